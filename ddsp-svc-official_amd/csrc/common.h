@@ -1,0 +1,85 @@
+// Shared host/device helpers for libddsp_amd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/ddsp_amd.h"
+
+#define DDSP_WAVE 64
+
+// Opaque handle behind ddsp_ctx: device scratch that outlives a call, DFT tables keyed by
+// filter length, and the last error text.  One handle per stream/thread (SURVEY 8b "Threading").
+struct ddsp_table {
+    int kind;          // table family (see tables.hip)
+    int n0, n1;        // key
+    float* dev;        // device pointer
+    size_t bytes;
+};
+
+struct ddsp_ctx {
+    int device;
+    char err[512];
+    // bump-allocated scratch, grown on demand between calls (never inside a captured region)
+    char* scratch;
+    size_t scratch_bytes;
+    size_t scratch_used;
+    ddsp_table tables[64];
+    int n_tables;
+    // packed control-net weights (prepared by ddsp_u2c_prepare)
+    float* packed;
+    size_t packed_bytes;
+};
+
+static inline int ddsp_fail(ddsp_ctx* ctx, int code, const char* what, const char* detail) {
+    if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s: %s", what, detail ? detail : "");
+    return code;
+}
+
+#define DDSP_HIP(ctx, call)                                                     \
+    do {                                                                        \
+        hipError_t e_ = (call);                                                 \
+        if (e_ != hipSuccess) return ddsp_fail(ctx, DDSP_ERR_HIP, #call, hipGetErrorString(e_)); \
+    } while (0)
+
+#define DDSP_REQUIRE(ctx, cond, msg)                                            \
+    do {                                                                        \
+        if (!(cond)) return ddsp_fail(ctx, DDSP_ERR_ARG, msg, #cond);           \
+    } while (0)
+
+#define DDSP_LAUNCH_CHECK(ctx)                                                  \
+    do {                                                                        \
+        hipError_t e_ = hipGetLastError();                                      \
+        if (e_ != hipSuccess) return ddsp_fail(ctx, DDSP_ERR_HIP, "kernel launch", hipGetErrorString(e_)); \
+    } while (0)
+
+// scratch (ctx.hip)
+int ddsp_scratch_reset(ddsp_ctx* ctx);
+int ddsp_scratch_get(ddsp_ctx* ctx, size_t bytes, void** out);
+int ddsp_scratch_reserve_bytes(ddsp_ctx* ctx, size_t bytes);
+// tables (tables.hip)
+int ddsp_get_table(ddsp_ctx* ctx, hipStream_t st, int kind, int n0, int n1, float** out);
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+#ifdef __HIPCC__
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+#endif

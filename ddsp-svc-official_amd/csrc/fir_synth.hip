@@ -1,0 +1,106 @@
+// a5-a6: control frames -> linear-phase FIR frames (ctrl activation + inverse real DFT + window).
+//
+// Replaces ddsp/vocoder.py:521-523 (pi*tanh / exp / exp/128), `exp(1j*cumsum(group_delay))` (:540) and
+// ddsp/core.py:306-328 `_frequency_impulse_response` with its three window branches (:242-289, :292-303).
+// n = 2*(n_mag-1) is 510 or 1022 (not FFT-friendly: 2*3*5*17, 2*7*73), and the transform is applied to
+// 11k frames at once, so it is a dense contraction against a constant matrix: IR = act(ctrl) x T on the
+// fp32 matrix pipe (gemm_f32.h), T from tables.hip with the n/2 rotation and the static Hann folded in.
+// The dynamic raised-cosine window depends on the frame's f0 and is applied in the GEMM epilogue.
+#include "gemm_f32.h"
+#include "tables.h"
+
+namespace {
+
+// One wavefront per frame row.  REAL modes: out[f] = exp(ctrl[f]) * scale.
+// ALLPASS: gd = pi*tanh(ctrl); phi = cumsum_f(gd) (fp64 running sum rounded to fp32 per bin, as ATen's
+// CPU cumsum does); out = [cos(phi) | sin(phi)].
+__global__ void __launch_bounds__(256) fir_act_kernel(int mode, const float* __restrict__ ctrl, int64_t ld, int M,
+                                                      int ldo, int64_t rows, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* src = ctrl + row * ld;
+    if (mode != DDSP_FIR_ALLPASS) {
+        float* dst = out + row * ldo;
+        const float scale = (mode == DDSP_FIR_STATIC) ? (1.0f / 128.0f) : 1.0f;
+        for (int f = lane; f < M; f += 64) dst[f] = expf(src[f]) * scale;  // /128 is exact scaling
+        return;
+    }
+    float* dst = out + row * ldo;
+    const float pi_f = 3.14159274101257324f;
+    double carry = 0.0;
+    for (int f0 = 0; f0 < M; f0 += 64) {
+        const int f = f0 + lane;
+        const float gd = (f < M) ? __fmul_rn(pi_f, tanhf(src[f])) : 0.f;
+        double incl = (double)gd;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            double nb = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += nb;
+        }
+        const float phi = (float)(carry + incl);
+        carry += __shfl(incl, 63, 64);
+        if (f < M) {
+            double s, c;
+            sincos((double)phi, &s, &c);
+            dst[f] = (float)c;
+            dst[M + f] = (float)s;
+        }
+    }
+}
+
+struct EpiDynWindow {  // ddsp/core.py:292-303 incl. its quirk: w>1 is zeroed BEFORE the cosine, w<-1 is not clamped
+    float* ir;
+    int n;
+    const float* f0;  // per row
+    float sr15;       // 1.5 * sr as fp32
+    __device__ __forceinline__ void operator()(int, int m, int k, float v) const {
+        const float hw = __fdiv_rn(sr15, __fadd_rn(f0[m], 1e-3f));
+        float w = __fdiv_rn((float)(k - n / 2), hw);
+        if (w > 1.0f) w = 0.0f;
+        const float win = __fdiv_rn(__fadd_rn(1.0f, cosf(__fmul_rn(3.14159274101257324f, w))), 2.0f);
+        ir[(int64_t)m * n + k] = __fmul_rn(v, win);
+    }
+};
+
+}  // namespace
+
+extern "C" int ddsp_fir_from_ctrl(ddsp_ctx* ctx, void* stream, int mode, const float* ctrl, int64_t ctrl_ld,
+                                  int n_mag, const float* f0_frames, int64_t rows, int sr, float* ir) {
+    DDSP_REQUIRE(ctx, ctx && ctrl && ir, "ddsp_fir_from_ctrl: null argument");
+    DDSP_REQUIRE(ctx, mode >= 0 && mode <= 2, "ddsp_fir_from_ctrl: unknown mode");
+    DDSP_REQUIRE(ctx, n_mag >= 3 && n_mag <= 1024 && ctrl_ld >= n_mag && rows >= 0 && rows < (1 << 30),
+                 "ddsp_fir_from_ctrl: bad shape");
+    DDSP_REQUIRE(ctx, mode != DDSP_FIR_DYNAMIC || f0_frames, "ddsp_fir_from_ctrl: DYNAMIC needs f0_frames");
+    if (rows == 0) return DDSP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    const int M = n_mag, n = 2 * (n_mag - 1);
+    const int K = (mode == DDSP_FIR_ALLPASS) ? 2 * M : M;
+    const int lda = ddsp_pad4(K);
+    int rc = ddsp_scratch_reserve_bytes(ctx, (size_t)rows * lda * sizeof(float) + 4096);
+    if (rc) return rc;
+    ddsp_scratch_reset(ctx);
+    float* act = nullptr;
+    rc = ddsp_scratch_get(ctx, (size_t)rows * lda * sizeof(float), (void**)&act);
+    if (rc) return rc;
+    float* tab = nullptr;
+    const int kind = mode == DDSP_FIR_ALLPASS ? TAB_IRDFT_CPLX : (mode == DDSP_FIR_STATIC ? TAB_IRDFT_RE_HANN : TAB_IRDFT_RE);
+    rc = ddsp_get_table(ctx, st, kind, M, 0, &tab);
+    if (rc) return rc;
+
+    hipLaunchKernelGGL(fir_act_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, mode, ctrl, ctrl_ld, M,
+                       lda, rows, act);
+    DDSP_LAUNCH_CHECK(ctx);
+
+    gemm::Args g = gemm::make(act, lda, tab, ddsp_pad4(n), (int)rows, n, K);
+    if (mode == DDSP_FIR_DYNAMIC) {
+        EpiDynWindow epi{ir, n, f0_frames, 1.5f * (float)sr};
+        gemm::launch<true, false, gemm::A_PLAIN>(st, g, 1, epi);
+    } else {
+        gemm::EpiStore epi{ir, n, nullptr, 1, 0, 0};
+        gemm::launch<true, false, gemm::A_PLAIN>(st, g, 1, epi);
+    }
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}

@@ -1,0 +1,210 @@
+// a7: frame-varying FIR on the fp32 matrix pipe (Toeplitz-block products, v_mfma_f32_16x16x4_f32).
+//
+// Replaces ddsp/core.py:185-239 `_fft_convolve` + :147-182 `_crop_and_compensate_delay`.
+// The reference frames the input at 50% overlap with a triangular window, multiplies spectra
+// (FFT length 2*hop+n-1) and overlap-adds; any zero-padded length gives the same linear convolution,
+// so this kernel evaluates it directly, output-stationary:
+//
+//   out[u] = sum_m sum_k  ir[min(m,Fr-1)][k] * xw_m[u + n/2 - k],   xw_m[t] = x[t] * tri(t - hop*(m-1))
+//
+// with tri the periodic Bartlett window of length 2*hop and m = 0..Fr (frame Fr reuses filter Fr-1).
+//
+// MFMA mapping.  Time is cut into columns of 16 samples.  For an output tile O[i][j] = out[16*(J0+j)+i]
+// (16x16 = 256 samples, one wavefront) and a column shift q, the contribution of frame m is
+//   O += A_q * B_q,  A_q[i][r] = ir_m[16q + n/2 + i - r] (a Toeplitz block),  B_q[r][j] = xw_m[16*(J0+j-q) + r],
+// i.e. one K=16 product = four 16x16x4 MFMAs.  Only (m, q) pairs whose 16 input columns touch frame m's
+// 64-column support are issued (about 80% of the issued MACs are useful; the rest multiply zero pad).
+// LDS holds, per frame of the block: the filter row with 32 zeros either side, and the pre-windowed
+// input transposed to [r][col] with row stride 112 (= 16 mod 32) plus a 2*(r>>1) column skew, which
+// makes both the fill (lanes along t) and the B-operand fetch (lanes along col, rows r and r+1)
+// conflict-free.  Outputs leave as one float4 per lane, 1 KiB contiguous per wavefront.
+//
+// Bound: fp32 matrix pipe (64 FLOP/clk/SIMD); algorithmic HBM bytes are 4 B in + 4 B out per sample plus
+// 4*n/hop B of filter per sample.
+#include "common.h"
+
+namespace {
+
+constexpr int HOP = 512;
+constexpr int HOPC = HOP / 16;  // 32 columns per hop
+constexpr int PADC = 16;
+constexpr int RS = 112;         // row stride of the transposed input image (floats)
+constexpr int XS = 16 * RS;     // floats per frame image
+constexpr int IRPAD = 32;
+constexpr int SEG = 2;          // segments (hops) per block: 4 wavefronts, one 256-sample tile each
+
+__device__ __forceinline__ float noise_u(uint64_t seed, uint64_t idx) {
+    // splitmix64 finaliser of a counter: stateless, so every block that needs sample idx regenerates it
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    float u = (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);  // 24-bit U[0,1) like torch.rand fp32
+    return u * 2.0f - 1.0f;                                       // exact in fp32
+}
+
+struct FirArgs {
+    const float* audio;  // (B,T) or null
+    int excitation;      // DDSP_EXC_*
+    uint64_t seed;
+    const float* ir;     // (B,Fr,n)
+    const float* add_in; // (B,T) or null
+    float* out;          // (B,T) or null: filtered signal
+    float* out_sum;      // (B,T) or null: filtered signal + add_in
+    int Fr, n;
+    int q_lo, q_hi;      // column-shift range of the filter
+    int nfr;             // frames staged per block
+    int m_off;           // first staged frame relative to the block's first segment
+    int irs;             // floats per staged filter row (n + 2*IRPAD, rounded)
+};
+
+__global__ void __launch_bounds__(64 * 2 * SEG) ltv_fir_kernel(FirArgs g) {
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int s0 = blockIdx.x * SEG;  // first segment of the block
+    const int64_t T = (int64_t)g.Fr * HOP;
+    const int c = g.n / 2;
+
+    // frames whose 64-column support can reach this block's outputs: m in [m_lo, m_lo + nfr)
+    // (input columns touched: [32*s0 - q_hi, 32*(s0+SEG) - 1 - q_lo]; m_off = -ceil(q_hi/32))
+    const int m_lo = s0 + g.m_off;
+    float* irs = lds;                          // [nfr][g.irs]
+    float* xs = lds + (size_t)g.nfr * g.irs;   // [nfr][XS]
+
+    // ---- stage filters and windowed input ----------------------------------------------------
+    for (int f = 0; f < g.nfr; ++f) {
+        const int m = m_lo + f;
+        const bool live = (m >= 0 && m <= g.Fr);
+        const int mi = m < g.Fr ? m : g.Fr - 1;
+        const float* src = g.ir + ((int64_t)b * g.Fr + (live ? mi : 0)) * g.n;
+        float* dst = irs + (size_t)f * g.irs;
+        for (int i = tid; i < g.irs; i += blockDim.x) {
+            const int k = i - IRPAD;
+            dst[i] = (live && k >= 0 && k < g.n) ? src[k] : 0.f;
+        }
+        float* xd = xs + (size_t)f * XS;
+        for (int i = tid; i < XS; i += blockDim.x) xd[i] = 0.f;
+    }
+    __syncthreads();
+    for (int f = 0; f < g.nfr; ++f) {
+        const int m = m_lo + f;
+        if (m < 0 || m > g.Fr) continue;
+        float* xd = xs + (size_t)f * XS;
+        const int64_t tb = (int64_t)HOP * (m - 1);
+        for (int z = tid; z < 2 * HOP; z += blockDim.x) {
+            const int64_t t = tb + z;
+            float x = 0.f;
+            if (t >= 0 && t < T) {
+                if (g.excitation == DDSP_EXC_GENERATE) {
+                    x = noise_u(g.seed, (uint64_t)b * T + t);
+                } else {
+                    x = g.audio[(int64_t)b * T + t];
+                    if (g.excitation == DDSP_EXC_UNIT_NOISE) x = __fadd_rn(__fmul_rn(x, 2.0f), -1.0f);
+                }
+            }
+            const float w = (z < HOP) ? (float)z * (1.0f / HOP) : (float)(2 * HOP - z) * (1.0f / HOP);
+            const int r = z & 15, col = z >> 4;
+            xd[r * RS + PADC + col + 2 * (r >> 1)] = x * w;
+        }
+    }
+    __syncthreads();
+
+    const int seg = s0 + (wave >> 1);
+    if (seg >= g.Fr) return;
+    const int J0 = HOPC * seg + 16 * (wave & 1);  // first output column of this wavefront's tile
+    const int li = lane & 15, lk = lane >> 4;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // lane-constant parts of the operand addresses, per k-step s (r = 4s + lk)
+    int a_off[4], b_off[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int r = 4 * s + lk;
+        a_off[s] = IRPAD + c + li - r;
+        b_off[s] = r * RS + PADC + 2 * (r >> 1) + li;
+    }
+
+    for (int f = 0; f < g.nfr; ++f) {
+        const int m = m_lo + f;
+        if (m < 0 || m > g.Fr) continue;
+        const int cbase = HOPC * (m - 1);  // absolute column of the frame image's column 0
+        int qa = J0 - (cbase + 2 * HOPC) + 1;
+        int qb = J0 + 15 - cbase;
+        if (qa < g.q_lo) qa = g.q_lo;
+        if (qb > g.q_hi) qb = g.q_hi;
+        const float* ap = irs + (size_t)f * g.irs;
+        const float* bp = xs + (size_t)f * XS + (J0 - cbase);
+#pragma unroll 2
+        for (int q = qa; q <= qb; ++q) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float a = ap[16 * q + a_off[s]];
+                const float bv = bp[b_off[s] - q];
+                acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[s], 0, 0, 0);
+            }
+        }
+    }
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
+    // C/D map of the 16x16 MFMA: col = lane & 15, row = 4*(lane >> 4) + reg
+    const int64_t u = (int64_t)b * T + 16 * (int64_t)(J0 + li) + 4 * lk;
+    if (g.out) *(f32x4*)(g.out + u) = o;
+    if (g.out_sum) {
+        const f32x4 ad = *(const f32x4*)(g.add_in + u);
+        *(f32x4*)(g.out_sum + u) = ad + o;
+    }
+}
+
+}  // namespace
+
+extern "C" int ddsp_ltv_fir(ddsp_ctx* ctx, void* stream, const float* audio, int excitation, uint64_t noise_seed,
+                            const float* ir, int64_t B, int64_t Fr, int hop, int n, const float* add_in, float* out,
+                            float* out_sum) {
+    DDSP_REQUIRE(ctx, ctx && ir && (out || out_sum), "ddsp_ltv_fir: null argument");
+    DDSP_REQUIRE(ctx, excitation >= 0 && excitation <= 2, "ddsp_ltv_fir: unknown excitation");
+    DDSP_REQUIRE(ctx, (excitation == DDSP_EXC_GENERATE) || audio, "ddsp_ltv_fir: audio is null");
+    DDSP_REQUIRE(ctx, (out_sum == nullptr) == (add_in == nullptr), "ddsp_ltv_fir: out_sum and add_in go together");
+    DDSP_REQUIRE(ctx, hop == HOP, "ddsp_ltv_fir: only hop == 512 is built");
+    DDSP_REQUIRE(ctx, n >= 32 && n <= 2046 && (n % 2) == 0, "ddsp_ltv_fir: n must be even, 32..2046");
+    DDSP_REQUIRE(ctx, B >= 0 && Fr >= 1 && B <= 65535, "ddsp_ltv_fir: bad shape");
+    DDSP_REQUIRE(ctx, ((uintptr_t)out % 16) == 0 && ((uintptr_t)add_in % 16) == 0 && ((uintptr_t)out_sum % 16) == 0,
+                 "ddsp_ltv_fir: out/add_in/out_sum must be 16-byte aligned");
+    if (B == 0) return DDSP_OK;
+    FirArgs g;
+    g.audio = audio;
+    g.excitation = excitation;
+    g.seed = noise_seed;
+    g.ir = ir;
+    g.add_in = add_in;
+    g.out = out;
+    g.out_sum = out_sum;
+    g.Fr = (int)Fr;
+    g.n = n;
+    const int c = n / 2;
+    g.q_lo = -((c + 15) / 16);
+    g.q_hi = (c + 14) / 16;
+    // input columns touched by one block: [32*s0 - q_hi, 32*(s0+SEG) - 1 - q_lo]
+    g.m_off = -((g.q_hi + HOPC - 1) / HOPC);
+    g.nfr = SEG + (-1 - g.q_lo) / HOPC + 1 - g.m_off + 1;
+    g.irs = (n + 2 * IRPAD + 3) & ~3;
+    const size_t lds_bytes = (size_t)g.nfr * (g.irs + XS) * sizeof(float);
+    DDSP_REQUIRE(ctx, lds_bytes <= 160 * 1024, "ddsp_ltv_fir: filter too long for the LDS staging");
+    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    static bool attr_set = false;
+    if (!attr_set) {
+        DDSP_HIP(ctx, hipFuncSetAttribute((const void*)ltv_fir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          160 * 1024));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)((Fr + SEG - 1) / SEG), (unsigned)B);
+    hipLaunchKernelGGL(ltv_fir_kernel, grid, dim3(64 * 2 * SEG), lds_bytes, (hipStream_t)stream, g);
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}

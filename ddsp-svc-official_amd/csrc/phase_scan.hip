@@ -1,0 +1,233 @@
+// a1-a3: frame->sample upsampler, fp64 wavefront-prefix-summed phase integrator, combtooth.
+//
+// Replaces (reference paths): ddsp/core.py:7-21 upsample, ddsp/core.py:31-51 fo_to_rot,
+// ddsp/vocoder.py:517 phase_frames, ddsp/vocoder.py:539 / :459-460 combtooth.
+//
+// Layout: f0 frames (B,Fr) are the only HBM input (4 B per 512 output samples); every per-sample
+// quantity is recomputed from the two bracketing frame values in registers.  One wavefront owns one
+// frame (hop samples, 8 consecutive per lane for hop=512): pass 1 reduces the frame's fp64 increment
+// sum, pass 2 adds the exclusive prefix of the preceding frame sums of the same utterance and does
+// the in-frame scan with a 64-lane fp64 shuffle scan.  Outputs are written 16 B per lane.
+#include "common.h"
+
+namespace {
+
+constexpr int WAVES_PER_BLOCK = 4;
+
+// ATen's align_corners linear kernel: src = scale*dst, w1 = src - floor(src), w0 = 1 - w1,
+// out = fma(w0, x0, w1*x1) (bit-exact with the CPU path on this image, tests/test_oracle_dsp.py).
+__device__ __forceinline__ float lerp_frame(float x0, float x1, float w1) {
+    return __fmaf_rn(1.0f - w1, x0, __fmul_rn(w1, x1));
+}
+
+__device__ __forceinline__ double wave_excl_scan_d(double v, int lane) {
+    double incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        double n = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += n;
+    }
+    return incl - v;
+}
+
+template <bool PRECISE>
+__device__ __forceinline__ double increment(float f, float srf, double srd) {
+    if (PRECISE) return (double)f / srd;
+    return (double)__fdiv_rn(f, srf);
+}
+
+// pass 1: frame_sum[b][m] = sum_j inc(b, m*hop + j)
+template <bool PRECISE>
+__global__ void __launch_bounds__(256) frame_sum_kernel(const float* __restrict__ f0_frames, int64_t n_frames_total,
+                                                        int Fr, int hop, float scale, int sr,
+                                                        double* __restrict__ frame_sum) {
+    const int lane = threadIdx.x & 63;
+    const int64_t fidx = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (fidx >= n_frames_total) return;
+    const int m = (int)(fidx % Fr);
+    const float x0 = f0_frames[fidx];
+    const float x1 = (m + 1 < Fr) ? f0_frames[fidx + 1] : x0;
+    const float srf = (float)sr;
+    const double srd = (double)sr;
+    double acc = 0.0;
+    const int per_lane = (hop + 63) / 64;
+    for (int i = 0; i < per_lane; ++i) {
+        int j = lane * per_lane + i;
+        if (j < hop) {
+            float src = __fmul_rn(scale, (float)(m * hop + j));
+            float w1 = src - (float)m;
+            acc += increment<PRECISE>(lerp_frame(x0, x1, w1), srf, srd);
+        }
+    }
+    acc = wave_sum_d(acc);
+    if (lane == 0) frame_sum[fidx] = acc;
+}
+
+struct ScanOut {
+    float* rot;
+    float* phase;
+    float* comb;
+    float* f0_up;
+    float* phase_frames;
+};
+
+template <bool PRECISE>
+__global__ void __launch_bounds__(256) frame_scan_kernel(const float* __restrict__ f0_frames,
+                                                         const double* __restrict__ frame_sum,
+                                                         const float* __restrict__ initial_phase,
+                                                         int64_t n_frames_total, int Fr, int hop, float scale, int sr,
+                                                         int comb_mode, ScanOut out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t fidx = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (fidx >= n_frames_total) return;
+    const int64_t b = fidx / Fr;
+    const int m = (int)(fidx % Fr);
+    const float x0 = f0_frames[fidx];
+    const float x1 = (m + 1 < Fr) ? f0_frames[fidx + 1] : x0;
+    const float srf = (float)sr;
+    const double srd = (double)sr;
+
+    // exclusive prefix over the preceding frames of this utterance
+    double before = 0.0;
+    for (int i = lane; i < m; i += 64) before += frame_sum[b * Fr + i];
+    before = wave_sum_d(before);
+
+    const int per_lane = (hop + 63) / 64;  // host guarantees per_lane <= 16
+    float fval[16];
+    double local[16];
+    double run = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i < per_lane) {
+            int j = lane * per_lane + i;
+            float f = 0.f;
+            double inc = 0.0;
+            if (j < hop) {
+                float src = __fmul_rn(scale, (float)(m * hop + j));
+                float w1 = src - (float)m;
+                f = lerp_frame(x0, x1, w1);
+                inc = increment<PRECISE>(f, srf, srd);
+            }
+            run += inc;
+            fval[i] = f;
+            local[i] = run;
+        }
+    }
+    const double base = before + wave_excl_scan_d(run, lane);
+
+    double init_d = 0.0;
+    float init_f = 0.f;
+    const bool has_init = initial_phase != nullptr;
+    if (has_init) {
+        float ip = initial_phase[b];
+        init_d = (double)ip / 2.0 / 3.141592653589793;              // .to(fp64)/2/np.pi
+        init_f = __fdiv_rn(__fdiv_rn(ip, 2.0f), 3.14159274101257324f);  // fp32 /2 /np.pi
+    }
+    const float two_pi_f = 6.28318548202514648f;  // fp32(2*np.pi)
+    const float pi_f = 3.14159274101257324f;
+    const int64_t t0 = fidx * (int64_t)hop;
+
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i < per_lane) {
+            int j = lane * per_lane + i;
+            if (j < hop) {
+                double S = base + local[i];
+                float r;
+                if (PRECISE) {
+                    if (has_init) S += init_d;
+                    r = (float)(S - rint(S));
+                } else {
+                    float Sf = (float)S;  // ATen CPU cumsum: fp64 accumulator, fp32 output per element
+                    if (has_init) Sf = __fadd_rn(Sf, init_f);
+                    r = Sf - rintf(Sf);
+                }
+                const int64_t t = t0 + j;
+                if (out.rot) out.rot[t] = r;
+                const float ph = __fmul_rn(two_pi_f, r);
+                if (out.phase) out.phase[t] = ph;
+                if (j == 0) out.phase_frames[fidx] = ph;
+                if (out.f0_up) out.f0_up[t] = fval[i];
+                if (out.comb) {
+                    float x = __fdiv_rn(__fmul_rn(srf, r), __fadd_rn(fval[i], 1e-3f));
+                    float p = __fmul_rn(pi_f, x);
+                    float c = (x == 0.0f) ? 1.0f : __fdiv_rn(sinf(p), p);
+                    if (comb_mode == DDSP_COMB_SINC_GATED && fval[i] <= 0.0f) c = 0.0f;
+                    out.comb[t] = c;
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) upsample_kernel(const float* __restrict__ x, int64_t B, int64_t Fr, int64_t C,
+                                                       int hop, float scale, float* __restrict__ out) {
+    // one thread per output element, channels fastest (coalesced on C, or on t when C == 1)
+    const int64_t total = B * Fr * hop * C;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = idx % C;
+        const int64_t t = (idx / C) % (Fr * hop);
+        const int64_t b = idx / (C * Fr * hop);
+        const float src = __fmul_rn(scale, (float)t);
+        const int64_t i0 = (int64_t)src;
+        const int64_t i1 = (i0 + 1 < Fr) ? i0 + 1 : Fr - 1;
+        const float w1 = src - (float)i0;
+        const float* row = x + b * Fr * C;
+        out[idx] = lerp_frame(row[i0 * C + c], row[i1 * C + c], w1);
+    }
+}
+
+}  // namespace
+
+extern "C" int ddsp_upsample(ddsp_ctx* ctx, void* stream, const float* x, int64_t B, int64_t Fr, int64_t C, int hop,
+                             float* out) {
+    DDSP_REQUIRE(ctx, ctx && x && out, "ddsp_upsample: null argument");
+    DDSP_REQUIRE(ctx, B >= 0 && Fr >= 1 && C >= 1 && hop >= 1, "ddsp_upsample: bad shape");
+    DDSP_REQUIRE(ctx, Fr * (int64_t)hop < (1 << 24), "ddsp_upsample: Fr*hop must stay below 2^24 (fp32 index grid)");
+    if (B == 0) return DDSP_OK;
+    const float scale = (float)Fr / (float)(Fr * hop);
+    const int64_t total = B * Fr * hop * C;
+    int64_t blocks = ceil_div64(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, B, Fr, C, hop,
+                       scale, out);
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}
+
+extern "C" int ddsp_phase_scan(ddsp_ctx* ctx, void* stream, const float* f0_frames, const float* initial_phase,
+                               int64_t B, int64_t Fr, int hop, int sr, int precise, int comb_mode, float* rot,
+                               float* phase, float* comb, float* f0_up, float* phase_frames) {
+    DDSP_REQUIRE(ctx, ctx && f0_frames && phase_frames, "ddsp_phase_scan: null argument");
+    DDSP_REQUIRE(ctx, B >= 0 && Fr >= 1 && hop >= 1 && hop <= 1024 && sr > 0, "ddsp_phase_scan: bad shape");
+    DDSP_REQUIRE(ctx, Fr * (int64_t)hop < (1 << 24), "ddsp_phase_scan: Fr*hop must stay below 2^24");
+    DDSP_REQUIRE(ctx, comb_mode >= 0 && comb_mode <= 2, "ddsp_phase_scan: unknown comb_mode");
+    DDSP_REQUIRE(ctx, (comb_mode == DDSP_COMB_NONE) == (comb == nullptr), "ddsp_phase_scan: comb buffer vs comb_mode");
+    if (B == 0) return DDSP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nf = B * Fr;
+    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ddsp_scratch_reserve_bytes(ctx, (size_t)nf * sizeof(double) + 4096);
+    if (rc) return rc;
+    ddsp_scratch_reset(ctx);
+    double* fsum = nullptr;
+    rc = ddsp_scratch_get(ctx, (size_t)nf * sizeof(double), (void**)&fsum);
+    if (rc) return rc;
+    const float scale = (float)Fr / (float)(Fr * hop);
+    const unsigned blocks = (unsigned)ceil_div64(nf, WAVES_PER_BLOCK);
+    ScanOut o{rot, phase, comb, f0_up, phase_frames};
+    if (precise) {
+        hipLaunchKernelGGL(frame_sum_kernel<true>, dim3(blocks), dim3(256), 0, st, f0_frames, nf, (int)Fr, hop, scale,
+                           sr, fsum);
+        hipLaunchKernelGGL(frame_scan_kernel<true>, dim3(blocks), dim3(256), 0, st, f0_frames, fsum, initial_phase, nf,
+                           (int)Fr, hop, scale, sr, comb_mode, o);
+    } else {
+        hipLaunchKernelGGL(frame_sum_kernel<false>, dim3(blocks), dim3(256), 0, st, f0_frames, nf, (int)Fr, hop, scale,
+                           sr, fsum);
+        hipLaunchKernelGGL(frame_scan_kernel<false>, dim3(blocks), dim3(256), 0, st, f0_frames, fsum, initial_phase,
+                           nf, (int)Fr, hop, scale, sr, comb_mode, o);
+    }
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}

@@ -1,0 +1,206 @@
+"""`Unit2Control` with the reference's constructor, state-dict keys and forward contract
+(reference `ddsp/unit2control.py:23-101`, `ddsp/pcmer.py`), executed by libddsp_amd.
+
+The torch modules below are PARAMETER CONTAINERS only (their names reproduce the reference's
+state-dict layout so upstream checkpoints load with `load_state_dict`); none of them has a forward of
+its own.  `Unit2Control.forward` hands raw device pointers to `ddsp_unit2ctrl_fwd`.
+Only the non-causal configuration (`c: false`, every shipped config) exists; `c=True` raises.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+import hipddsp
+
+NDIM = 256
+N_LAYERS = 3
+N_HEADS = 8
+HEAD_DIM = 64
+N_FEATURES = int(HEAD_DIM * math.log(HEAD_DIM))  # 266 random features (reference ddsp/pcmer.py:196)
+DW_KERNEL = 31
+
+
+class _Slot(nn.Module):
+    """Placeholder keeping the index of a parameter-free layer inside an nn.Sequential."""
+
+
+def _uniform_(t, bound):
+    with torch.no_grad():
+        return t.uniform_(-bound, bound)
+
+
+class _Affine(nn.Module):
+    """weight/bias pair initialised like torch's Linear / Conv1d (kaiming-uniform, a=sqrt(5))."""
+
+    def __init__(self, w_shape, fan_in, ones=False):
+        super().__init__()
+        if ones:  # normalisation layers
+            self.weight = nn.Parameter(torch.ones(w_shape))
+            self.bias = nn.Parameter(torch.zeros(w_shape))
+        else:
+            bound = 1.0 / math.sqrt(fan_in)
+            self.weight = nn.Parameter(_uniform_(torch.empty(w_shape), bound))
+            self.bias = nn.Parameter(_uniform_(torch.empty(w_shape[0]), bound))
+
+
+class _WeightNormHead(nn.Module):
+    """Keys bias / weight_g / weight_v of the reference's `weight_norm(nn.Linear(...))` (:61)."""
+
+    def __init__(self, n_in, n_out):
+        super().__init__()
+        bound = 1.0 / math.sqrt(n_in)
+        v = _uniform_(torch.empty(n_out, n_in), bound)
+        self.bias = nn.Parameter(_uniform_(torch.empty(n_out), bound))
+        self.weight_g = nn.Parameter(v.norm(dim=1, keepdim=True).clone())
+        self.weight_v = nn.Parameter(v)
+
+
+def _orthogonal_gaussian_features(n_rows, n_cols):
+    """Performer projection: stacked orthogonal blocks with chi-distributed row norms (the construction
+    the reference uses for its fixed `projection_matrix` buffer, `ddsp/pcmer.py:80-120`)."""
+    blocks = []
+    remaining = n_rows
+    while remaining > 0:
+        q, _ = torch.linalg.qr(torch.randn(n_cols, n_cols), mode="reduced")
+        take = min(remaining, n_cols)
+        blocks.append(q.t()[:take])
+        remaining -= take
+    mat = torch.cat(blocks, dim=0)
+    norms = torch.randn(n_rows, n_cols).norm(dim=1)
+    return norms[:, None] * mat
+
+
+class _FastAttention(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("projection_matrix", _orthogonal_gaussian_features(N_FEATURES, HEAD_DIM))
+
+
+class _SelfAttention(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        inner = N_HEADS * HEAD_DIM
+        self.fast_attention = _FastAttention()
+        self.to_q = _Affine((inner, dim), dim)
+        self.to_k = _Affine((inner, dim), dim)
+        self.to_v = _Affine((inner, dim), dim)
+        self.to_out = _Affine((dim, inner), inner)
+
+
+class _ConvModule(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        inner = dim * 2
+        self.net = nn.Sequential(
+            _Affine((dim,), dim, ones=True),                 # 0 LayerNorm
+            _Slot(),                                         # 1 transpose
+            _Affine((inner * 2, dim, 1), dim),               # 2 pointwise conv
+            _Slot(),                                         # 3 GLU
+            _Affine((inner, 1, DW_KERNEL), DW_KERNEL),       # 4 depthwise conv
+            _Slot(),                                         # 5 SiLU
+            _Affine((dim, inner, 1), inner),                 # 6 pointwise conv
+            _Slot(), _Slot(),                                # 7 transpose, 8 dropout(p=0)
+        )
+
+
+class _EncoderLayer(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.norm = _Affine((dim,), dim, ones=True)
+        self.attn = _SelfAttention(dim)
+        self.local_mixer = _ConvModule(dim)
+
+
+class _PCmer(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.net = nn.Sequential(*[_EncoderLayer(dim) for _ in range(N_LAYERS)])
+
+
+def split_to_dict(tensor, tensor_splits):
+    """Views into the fused control matrix, in dict order (reference `ddsp/unit2control.py:10-20`)."""
+    out = {}
+    lo = 0
+    for name, width in tensor_splits.items():
+        out[name] = tensor[..., lo:lo + width]
+        lo += width
+    return out
+
+
+class Unit2Control(nn.Module):
+    def __init__(self, ndim_feat_i, n_spk, output_splits, c=False):
+        super().__init__()
+        if c:
+            raise ValueError("causal mode (c: true) is not built: the reference's causal Conv1dEx / "
+                             "fast_transformers semantics are unpinned (see DESIGN.md)")
+        self.n_unit = int(ndim_feat_i)
+        self.n_spk = int(n_spk)
+        self.output_splits = dict(output_splits)
+        self.n_out = sum(self.output_splits.values())
+        self.unit_prenet = nn.Sequential(
+            _Slot(),
+            _Affine((NDIM, self.n_unit, 3), self.n_unit * 3),
+            _Affine((NDIM,), NDIM, ones=True),               # GroupNorm(4, 256)
+            _Slot(),
+            _Affine((NDIM, NDIM, 3), NDIM * 3),
+            _Slot(),
+        )
+        self.f0_embed = _Affine((NDIM, 1), 1)
+        self.phase_embed = _Affine((NDIM, 1), 1)
+        self.volume_embed = _Affine((NDIM, 1), 1)
+        self.spk_embed = nn.Module()
+        self.spk_embed.weight = nn.Parameter(torch.randn(self.n_spk, NDIM))
+        self.dec_post = nn.Sequential(_PCmer(NDIM), _Affine((NDIM,), NDIM, ones=True),
+                                      _WeightNormHead(NDIM, self.n_out))
+        self._packed_version = None
+
+    # ---- raw pointer table ---------------------------------------------------------------------
+    def _weights_struct(self):
+        w = hipddsp.U2CWeights()
+        keep = []
+
+        def p(t):
+            if not t.is_cuda:
+                raise RuntimeError("Unit2Control parameters must live on a HIP device (no CPU fallback)")
+            t = t.detach()
+            if not t.is_contiguous() or t.dtype != torch.float32:
+                t = t.contiguous().float()
+            keep.append(t)
+            return t.data_ptr()
+
+        pre = self.unit_prenet
+        w.prenet_conv1_w, w.prenet_conv1_b = p(pre[1].weight), p(pre[1].bias)
+        w.prenet_gn_w, w.prenet_gn_b = p(pre[2].weight), p(pre[2].bias)
+        w.prenet_conv2_w, w.prenet_conv2_b = p(pre[4].weight), p(pre[4].bias)
+        w.f0_w, w.f0_b = p(self.f0_embed.weight), p(self.f0_embed.bias)
+        w.phase_w, w.phase_b = p(self.phase_embed.weight), p(self.phase_embed.bias)
+        w.volume_w, w.volume_b = p(self.volume_embed.weight), p(self.volume_embed.bias)
+        w.spk_table = p(self.spk_embed.weight)
+        w.n_spk, w.n_unit, w.n_out = self.n_spk, self.n_unit, self.n_out
+        for i, layer in enumerate(self.dec_post[0].net):
+            a, cm = layer.attn, layer.local_mixer.net
+            vals = dict(norm_w=layer.norm.weight, norm_b=layer.norm.bias,
+                        q_w=a.to_q.weight, q_b=a.to_q.bias, k_w=a.to_k.weight, k_b=a.to_k.bias,
+                        v_w=a.to_v.weight, v_b=a.to_v.bias, proj=a.fast_attention.projection_matrix,
+                        out_w=a.to_out.weight, out_b=a.to_out.bias,
+                        cm_ln_w=cm[0].weight, cm_ln_b=cm[0].bias, cm_pw1_w=cm[2].weight, cm_pw1_b=cm[2].bias,
+                        cm_dw_w=cm[4].weight, cm_dw_b=cm[4].bias, cm_pw2_w=cm[6].weight, cm_pw2_b=cm[6].bias)
+            for k, v in vals.items():
+                setattr(w, f"l{i}_{k}", p(v))
+        w.final_ln_w, w.final_ln_b = p(self.dec_post[1].weight), p(self.dec_post[1].bias)
+        head = self.dec_post[2]
+        w.head_g, w.head_v, w.head_b = p(head.weight_g), p(head.weight_v), p(head.bias)
+        return w, keep
+
+    def forward_flat(self, units, f0, phase, volume, spk_id, spk_mix_dict=None):
+        """(B, Fr, n_out) fused control matrix (the split views are taken by `forward`)."""
+        ctx = hipddsp.context_for(units.device)
+        w, keep = self._weights_struct()
+        return ctx.unit2ctrl(w, units, f0, phase, volume, spk_id, spk_mix_dict, self.n_out)
+
+    def forward(self, units, f0, phase, volume, spk_id, spk_mix_dict=None):
+        """Same contract as the reference `Unit2Control.forward` (`ddsp/unit2control.py:68-101`):
+        units (B,Fr,n_unit), f0 (B,Fr,1), phase (B,Fr), volume (B,Fr), spk_id (B,1)|(1,1) int64 1-based,
+        spk_mix_dict {id: weight} or None -> dict of (B,Fr,width) views."""
+        return split_to_dict(self.forward_flat(units, f0, phase, volume, spk_id, spk_mix_dict), self.output_splits)

@@ -1,0 +1,189 @@
+"""Drop-in for the synthesiser half of the reference's `ddsp/vocoder.py` (:335-550): `load_model`, `Sins`,
+`CombSub`, `CombSubFast`, `DotDict`, with the same constructors, `forward(...)` signature, return tuple and
+state-dict keys, executed by hand-written gfx950 kernels through libddsp_amd (no CPU fallback).
+
+Differences a caller can observe, all additive:
+  * `forward(..., noise=None, noise_seed=None)`: the reference draws its noise excitation from the CPU
+    mt19937 stream (`torch.rand_like`), which a GPU cannot reproduce.  `noise` (B,T) U[0,1) injects the
+    draw (parity runs); otherwise a counter-based in-kernel generator is used, seeded from torch's default
+    generator (so `torch.manual_seed` still makes a run repeatable) or from `noise_seed`.
+  * `c=True` (causal) raises ValueError.
+"""
+import os
+
+import torch
+import yaml
+
+import hipddsp
+from hipddsp import (COMB_SINC, COMB_SINC_GATED, COMB_NONE, EXC_AUDIO, EXC_GENERATE, EXC_UNIT_NOISE, FIR_ALLPASS,
+                     FIR_DYNAMIC, FIR_STATIC)
+
+from .unit2control import Unit2Control
+
+
+class DotDict(dict):
+    """Attribute access to nested config dicts (reference `ddsp/vocoder.py:335-341`)."""
+
+    def __getattr__(self, key):
+        val = self.get(key)
+        return DotDict(val) if type(val) is dict else val
+
+    __setattr__ = dict.__setitem__
+    __delattr__ = dict.__delitem__
+
+
+def load_model(model_path, device="cpu"):
+    """Reads `<dir>/config.yaml`, builds the model it names, loads `ckpt['model']`
+    (reference `ddsp/vocoder.py:343-369`).  Returns (model.eval(), args)."""
+    with open(os.path.join(os.path.split(model_path)[0], "config.yaml"), "r") as fh:
+        args = DotDict(yaml.safe_load(fh))
+    kind = args.model.type
+    if kind == "Sins":
+        model = Sins(sampling_rate=args.data.sampling_rate, block_size=args.data.block_size,
+                     n_harmonics=args.model.n_harmonics, n_mag_allpass=args.model.n_mag_allpass,
+                     n_mag_noise=args.model.n_mag_noise, n_unit=args.data.encoder_out_channels,
+                     n_spk=args.model.n_spk, c=args.model.c)
+    elif kind == "CombSub":
+        model = CombSub(sampling_rate=args.data.sampling_rate, block_size=args.data.block_size,
+                        n_mag_allpass=args.model.n_mag_allpass, n_mag_harmonic=args.model.n_mag_harmonic,
+                        n_mag_noise=args.model.n_mag_noise, n_unit=args.data.encoder_out_channels,
+                        n_spk=args.model.n_spk, c=args.model.c)
+    elif kind == "CombSubFast":
+        model = CombSubFast(sampling_rate=args.data.sampling_rate, block_size=args.data.block_size,
+                            n_unit=args.data.encoder_out_channels, n_spk=args.model.n_spk, c=args.model.c)
+    else:
+        raise ValueError(f" [x] Unknown Model: {kind}")
+    print(" [Loading] " + model_path)
+    # weights_only: a checkpoint is {'global_step', 'model', 'optimizer'} of tensors (reference logger/saver.py:83-87)
+    ckpt = torch.load(model_path, map_location=torch.device(device), weights_only=True)
+    model.to(device)
+    model.load_state_dict(ckpt["model"])
+    model.eval()
+    return model, args
+
+
+def _seed_from_torch():
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+class _SynthBase(torch.nn.Module):
+    def __init__(self, sampling_rate, block_size):
+        super().__init__()
+        self.register_buffer("sampling_rate", torch.tensor(sampling_rate))
+        self.register_buffer("block_size", torch.tensor(block_size))
+        self._sr = int(sampling_rate)
+        self._hop = int(block_size)
+
+    def _front(self, f0_frames, initial_phase, infer, comb_mode, **want):
+        if not f0_frames.is_cuda:
+            raise RuntimeError("the synthesiser runs on a HIP device only (no CPU fallback): move the model and its "
+                               "inputs to 'cuda'")
+        ctx = hipddsp.context_for(f0_frames.device)
+        return ctx, ctx.phase_scan(f0_frames, self._hop, self._sr, initial_phase, bool(infer), comb_mode, **want)
+
+    @staticmethod
+    def _noise_args(noise, noise_seed):
+        if noise is not None:
+            return noise.contiguous().float(), EXC_UNIT_NOISE, 0
+        return None, EXC_GENERATE, (_seed_from_torch() if noise_seed is None else int(noise_seed))
+
+
+class CombSub(_SynthBase):
+    """Combtooth subtractive synthesiser, classic variant (reference `ddsp/vocoder.py:495-550`)."""
+
+    def __init__(self, sampling_rate, block_size, n_mag_allpass, n_mag_harmonic, n_mag_noise, n_unit=256, n_spk=1,
+                 c=False):
+        super().__init__(sampling_rate, block_size)
+        print(" [DDSP Model] Combtooth Subtractive Synthesiser (Old Version)")
+        self.n_mags = (int(n_mag_allpass), int(n_mag_harmonic), int(n_mag_noise))
+        self.unit2ctrl = Unit2Control(n_unit, n_spk, {"group_delay": n_mag_allpass,
+                                                      "harmonic_magnitude": n_mag_harmonic,
+                                                      "noise_magnitude": n_mag_noise}, c)
+
+    def synth_from_ctrl(self, ctx, ctrl, f0_frames, comb, noise=None, noise_seed=None):
+        """DSP stage: fused control matrix (B,Fr,sum) + combtooth -> (signal, harmonic, noise)."""
+        B, Fr = ctrl.shape[0], ctrl.shape[1]
+        rows, sr, hop = B * Fr, self._sr, self._hop
+        na, nh, nn_ = self.n_mags
+        c2 = ctrl.reshape(rows, -1)
+        ir = ctx.fir_from_ctrl(FIR_ALLPASS, c2, 0, na, rows, sr)
+        h, _ = ctx.ltv_fir(comb, ir, B, Fr, hop)
+        ir = ctx.fir_from_ctrl(FIR_DYNAMIC, c2, na, nh, rows, sr, f0_frames)
+        harmonic, _ = ctx.ltv_fir(h, ir, B, Fr, hop)
+        ir = ctx.fir_from_ctrl(FIR_STATIC, c2, na + nh, nn_, rows, sr)
+        nz, exc, seed = self._noise_args(noise, noise_seed)
+        noise_out, signal = ctx.ltv_fir(nz, ir, B, Fr, hop, excitation=exc, noise_seed=seed, add_in=harmonic)
+        return signal, harmonic, noise_out
+
+    def forward(self, units_frames, f0_frames, volume_frames, spk_id, spk_mix_dict=None, initial_phase=None,
+                infer=True, noise=None, noise_seed=None, **kwargs):
+        """units (B,Fr,n_unit), f0 (B,Fr,1) Hz, volume (B,Fr), spk_id (B,1)|(1,1) int64 1-based ->
+        (signal (B,T), phase_frames (B,Fr,1), (harmonic (B,T), noise (B,T)))."""
+        ctx, ps = self._front(f0_frames, initial_phase, infer, COMB_SINC)
+        ctrl = self.unit2ctrl.forward_flat(units_frames, f0_frames, ps["phase_frames"], volume_frames, spk_id,
+                                           spk_mix_dict)
+        signal, harmonic, noise_out = self.synth_from_ctrl(ctx, ctrl, f0_frames, ps["comb"], noise, noise_seed)
+        return signal, ps["phase_frames"].unsqueeze(-1), (harmonic, noise_out)
+
+
+class Sins(_SynthBase):
+    """Sinusoids additive synthesiser (reference `ddsp/vocoder.py:372-423`)."""
+
+    def __init__(self, sampling_rate, block_size, n_harmonics, n_mag_allpass, n_mag_noise, n_unit=256, n_spk=1,
+                 c=False):
+        super().__init__(sampling_rate, block_size)
+        print(" [DDSP Model] Sinusoids Additive Synthesiser")
+        self.n_mags = (int(n_harmonics), int(n_mag_allpass), int(n_mag_noise))
+        self.unit2ctrl = Unit2Control(n_unit, n_spk, {"amplitudes": n_harmonics, "group_delay": n_mag_allpass,
+                                                      "noise_magnitude": n_mag_noise}, c)
+
+    def synth_from_ctrl(self, ctx, ctrl, f0_frames, phase, noise=None, noise_seed=None):
+        B, Fr = ctrl.shape[0], ctrl.shape[1]
+        rows, sr, hop = B * Fr, self._sr, self._hop
+        nhm, na, nn_ = self.n_mags
+        c2 = ctrl.reshape(rows, -1)
+        sinusoids = ctx.sins_bank(c2, 0, nhm, f0_frames, phase, B, Fr, hop, sr)
+        ir = ctx.fir_from_ctrl(FIR_ALLPASS, c2, nhm, na, rows, sr)
+        harmonic, _ = ctx.ltv_fir(sinusoids, ir, B, Fr, hop)
+        ir = ctx.fir_from_ctrl(FIR_STATIC, c2, nhm + na, nn_, rows, sr)
+        nz, exc, seed = self._noise_args(noise, noise_seed)
+        noise_out, signal = ctx.ltv_fir(nz, ir, B, Fr, hop, excitation=exc, noise_seed=seed, add_in=harmonic)
+        return signal, harmonic, noise_out
+
+    def forward(self, units_frames, f0_frames, volume_frames, spk_id, spk_mix_dict=None, initial_phase=None,
+                infer=True, max_upsample_dim=32, noise=None, noise_seed=None):
+        """Same contract as CombSub.forward except that the returned phase is sample-rate (B,T,1)
+        (reference `ddsp/vocoder.py:423`).  `max_upsample_dim` is accepted and ignored: the bank kernel never
+        materialises the (B,T,chunk) tensors the reference chunks to bound."""
+        ctx, ps = self._front(f0_frames, initial_phase, infer, COMB_NONE, want_phase=True)
+        ctrl = self.unit2ctrl.forward_flat(units_frames, f0_frames, ps["phase_frames"], volume_frames, spk_id,
+                                           spk_mix_dict)
+        signal, harmonic, noise_out = self.synth_from_ctrl(ctx, ctrl, f0_frames, ps["phase"], noise, noise_seed)
+        return signal, ps["phase"].unsqueeze(-1), (harmonic, noise_out)
+
+
+class CombSubFast(_SynthBase):
+    """Combtooth subtractive synthesiser, windowed spectral OLA variant (reference `ddsp/vocoder.py:426-492`)."""
+
+    def __init__(self, sampling_rate, block_size, n_unit=256, n_spk=1, c=False):
+        super().__init__(sampling_rate, block_size)
+        print(" [DDSP Model] Combtooth Subtractive Synthesiser")
+        self.register_buffer("window", torch.sqrt(torch.hann_window(2 * block_size)))
+        nb = int(block_size) + 1
+        self.unit2ctrl = Unit2Control(n_unit, n_spk, {"harmonic_magnitude": nb, "harmonic_phase": nb,
+                                                      "noise_magnitude": nb}, c)
+
+    def synth_from_ctrl(self, ctx, ctrl, comb, noise=None, noise_seed=None):
+        B, Fr = ctrl.shape[0], ctrl.shape[1]
+        nz, exc, seed = self._noise_args(noise, noise_seed)
+        return ctx.spectral_ola(ctrl.reshape(B * Fr, -1), comb, nz, exc, seed, B, Fr, self._hop)
+
+    def forward(self, units_frames, f0_frames, volume_frames, spk_id, spk_mix_dict=None, initial_phase=None,
+                infer=True, noise=None, noise_seed=None, **kwargs):
+        """Returns (signal, phase_frames (B,Fr,1), (signal, signal)) - the same tensor three times, like the
+        reference (`ddsp/vocoder.py:492`)."""
+        ctx, ps = self._front(f0_frames, initial_phase, infer, COMB_SINC_GATED)
+        ctrl = self.unit2ctrl.forward_flat(units_frames, f0_frames, ps["phase_frames"], volume_frames, spk_id,
+                                           spk_mix_dict)
+        signal = self.synth_from_ctrl(ctx, ctrl, ps["comb"], noise, noise_seed)
+        return signal, ps["phase_frames"].unsqueeze(-1), (signal, signal)

@@ -1,0 +1,190 @@
+"""ctypes binding of libddsp_amd.so (the C ABI declared in include/ddsp_amd.h).
+
+PyTorch is used only for device memory and streams: every call passes raw device pointers and the
+current HIP stream.  There is NO CPU fallback: without the shared library or without a GPU the
+calls raise.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libddsp_amd.so")
+
+DDSP_OK, DDSP_ERR_ARG, DDSP_ERR_HIP, DDSP_ERR_OOM = 0, -1, -2, -3
+
+COMB_NONE, COMB_SINC, COMB_SINC_GATED = 0, 1, 2
+FIR_ALLPASS, FIR_DYNAMIC, FIR_STATIC = 0, 1, 2
+EXC_AUDIO, EXC_UNIT_NOISE, EXC_GENERATE = 0, 1, 2
+
+_c = ctypes
+_vp, _i64, _u64, _int, _f32 = _c.c_void_p, _c.c_int64, _c.c_uint64, _c.c_int, _c.c_float
+
+
+class U2CWeights(_c.Structure):
+    """Mirror of `ddsp_u2c_weights` (include/ddsp_amd.h): device pointers into the state dict."""
+    _fields_ = (
+        [(n, _vp) for n in ("prenet_conv1_w", "prenet_conv1_b", "prenet_gn_w", "prenet_gn_b",
+                            "prenet_conv2_w", "prenet_conv2_b",
+                            "f0_w", "f0_b", "phase_w", "phase_b", "volume_w", "volume_b", "spk_table")]
+        + [("n_spk", _int), ("n_unit", _int), ("n_out", _int)]
+        + [(f"l{i}_{n}", _vp) for i in range(3) for n in (
+            "norm_w", "norm_b", "q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "proj", "out_w", "out_b",
+            "cm_ln_w", "cm_ln_b", "cm_pw1_w", "cm_pw1_b", "cm_dw_w", "cm_dw_b", "cm_pw2_w", "cm_pw2_b")]
+        + [(n, _vp) for n in ("final_ln_w", "final_ln_b", "head_g", "head_v", "head_b")]
+    )
+
+
+# name -> (restype, argtypes); every symbol declared in include/ddsp_amd.h must be listed here
+SIGNATURES = {
+    "ddsp_abi_version": (_int, []),
+    "ddsp_ctx_create": (_int, [_c.POINTER(_vp), _int]),
+    "ddsp_ctx_destroy": (_int, [_vp]),
+    "ddsp_last_error": (_c.c_char_p, [_vp]),
+    "ddsp_ctx_reserve": (_int, [_vp, _u64]),
+    "ddsp_upsample": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _int, _vp]),
+    "ddsp_phase_scan": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
+    "ddsp_fir_from_ctrl": (_int, [_vp, _vp, _int, _vp, _i64, _int, _vp, _i64, _int, _vp]),
+    "ddsp_ltv_fir": (_int, [_vp, _vp, _vp, _int, _u64, _vp, _i64, _i64, _int, _int, _vp, _vp, _vp]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library():
+    """Loads libddsp_amd.so from the package tree; raises if it has not been built."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    f"{LIB_PATH} is missing: build it with `python ddsp-svc-official_amd/hipddsp/build.py` "
+                    "(there is no CPU fallback for the synthesis path)")
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)   # AttributeError if the symbol is not exported
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libddsp_amd needs device tensors (no CPU fallback)")
+    if not t.is_contiguous():
+        raise ValueError("libddsp_amd needs contiguous tensors")
+    return t.data_ptr()
+
+
+class Context:
+    """One `ddsp_ctx` (scratch arena + constant tables) bound to a device; use one per stream/thread."""
+
+    def __init__(self, device):
+        self.lib = load_library()
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("libddsp_amd runs on a HIP device only (no CPU fallback); got device=%r" % (device,))
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: libddsp_amd cannot run (no CPU fallback)")
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        h = _vp()
+        rc = self.lib.ddsp_ctx_create(ctypes.byref(h), self.device.index)
+        if rc != DDSP_OK:
+            raise RuntimeError(f"ddsp_ctx_create failed with {rc}")
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.ddsp_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # -- helpers ------------------------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _check(self, rc, what):
+        if rc == DDSP_OK:
+            return
+        msg = self.lib.ddsp_last_error(self.handle)
+        msg = msg.decode() if msg else ""
+        if rc == DDSP_ERR_ARG:
+            raise ValueError(f"{what}: {msg}")
+        raise RuntimeError(f"{what} failed ({rc}): {msg}")
+
+    def call(self, name, *args):
+        rc = getattr(self.lib, name)(self.handle, self._stream(), *args)
+        self._check(rc, name)
+
+    # -- a1 ------------------------------------------------------------------------------------
+    def upsample(self, x, hop):
+        B, Fr, C = x.shape
+        x = x.contiguous().float()
+        out = torch.empty(B, Fr * hop, C, device=x.device, dtype=torch.float32)
+        self.call("ddsp_upsample", _ptr(x), B, Fr, C, int(hop), _ptr(out))
+        return out
+
+    # -- a1-a3 ---------------------------------------------------------------------------------
+    def phase_scan(self, f0_frames, hop, sr, initial_phase=None, precise=True, comb_mode=COMB_NONE,
+                   want_rot=False, want_phase=False, want_f0=False):
+        f0 = f0_frames.reshape(f0_frames.shape[0], -1).contiguous().float()
+        B, Fr = f0.shape
+        T = Fr * hop
+        dev = f0.device
+        mk = lambda: torch.empty(B, T, device=dev, dtype=torch.float32)
+        rot = mk() if want_rot else None
+        phase = mk() if want_phase else None
+        comb = mk() if comb_mode != COMB_NONE else None
+        f0_up = mk() if want_f0 else None
+        pf = torch.empty(B, Fr, device=dev, dtype=torch.float32)
+        ip = None if initial_phase is None else initial_phase.reshape(-1).contiguous().float()
+        self.call("ddsp_phase_scan", _ptr(f0), _ptr(ip), B, Fr, int(hop), int(sr), 1 if precise else 0,
+                  int(comb_mode), _ptr(rot), _ptr(phase), _ptr(comb), _ptr(f0_up), _ptr(pf))
+        return {"rot": rot, "phase": phase, "comb": comb, "f0_up": f0_up, "phase_frames": pf}
+
+    # -- a5-a6 ---------------------------------------------------------------------------------
+    def fir_from_ctrl(self, mode, ctrl2d, col0, n_mag, rows, sr, f0_frames=None):
+        """ctrl2d :: (rows, ld) contiguous; the filter's control values are columns [col0, col0+n_mag)."""
+        ld = ctrl2d.shape[-1]
+        n = 2 * (n_mag - 1)
+        ir = torch.empty(rows, n, device=ctrl2d.device, dtype=torch.float32)
+        base = _ptr(ctrl2d) + 4 * col0
+        f0 = None if f0_frames is None else f0_frames.reshape(-1).contiguous().float()
+        self.call("ddsp_fir_from_ctrl", int(mode), base, ld, int(n_mag), _ptr(f0), rows, int(sr), _ptr(ir))
+        return ir
+
+    # -- a7 ------------------------------------------------------------------------------------
+    def ltv_fir(self, audio, ir, B, Fr, hop, excitation=EXC_AUDIO, noise_seed=0, add_in=None, want_out=True):
+        """Returns (filtered | None, filtered + add_in | None)."""
+        n = ir.shape[-1]
+        mk = lambda: torch.empty(B, Fr * hop, device=ir.device, dtype=torch.float32)
+        out = mk() if want_out else None
+        out_sum = mk() if add_in is not None else None
+        self.call("ddsp_ltv_fir", _ptr(audio), int(excitation), int(noise_seed), _ptr(ir), B, Fr, int(hop), int(n),
+                  _ptr(add_in), _ptr(out), _ptr(out_sum))
+        return out, out_sum
+
+
+_contexts = {}
+_ctx_lock = threading.Lock()
+
+
+def context_for(device):
+    """Per (device, thread) context cache (one handle per stream/thread)."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    key = (dev.type, idx, threading.get_ident())
+    with _ctx_lock:
+        ctx = _contexts.get(key)
+        if ctx is None:
+            ctx = Context(torch.device(dev.type, idx) if dev.type == "cuda" else dev)
+            _contexts[key] = ctx
+    return ctx

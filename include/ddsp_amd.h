@@ -1,0 +1,93 @@
+/*
+ * libddsp_amd - C ABI of the MI355X (gfx950) DDSP harmonic-plus-noise synthesis path.
+ *
+ * The reference (tarepan/DDSP-SVC-official) has no FFI layer: its callers import Python names
+ * (`ddsp.vocoder.{load_model,Sins,CombSub,CombSubFast}`, `ddsp.core.upsample`, `ddsp.loss.RSSLoss`).
+ * This header is the boundary a binding for that path attaches to; each entry point names the
+ * reference code it replaces (paths relative to the reference root).  The Python mirror under
+ * `ddsp-svc-official_amd/ddsp/` binds it with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless the name ends in `_host`;
+ *   - tensors are dense, row-major, fp32 unless stated; sizes are element counts;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises
+ *     except scratch growth inside ddsp_ctx_reserve / the first call at a larger size;
+ *   - return value: DDSP_OK or a negative DDSP_ERR_*; ddsp_last_error() gives the text;
+ *   - one ddsp_ctx per stream/thread; a ctx holds scratch + constant tables, no model state.
+ */
+#ifndef DDSP_AMD_H
+#define DDSP_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDSP_OK 0
+#define DDSP_ERR_ARG (-1)   /* shape / mode / null-pointer contract violated (Python: ValueError)   */
+#define DDSP_ERR_HIP (-2)   /* a HIP runtime call or launch failed            (Python: RuntimeError) */
+#define DDSP_ERR_OOM (-3)   /* scratch allocation failed                      (Python: RuntimeError) */
+
+typedef struct ddsp_ctx ddsp_ctx;
+
+/* ---- handle ------------------------------------------------------------------------------- */
+int ddsp_ctx_create(ddsp_ctx** out, int device);
+int ddsp_ctx_destroy(ddsp_ctx* ctx);
+const char* ddsp_last_error(const ddsp_ctx* ctx);
+/* Pre-size the scratch arena (bytes).  Optional; calls grow it on demand (with a device sync). */
+int ddsp_ctx_reserve(ddsp_ctx* ctx, uint64_t bytes);
+int ddsp_abi_version(void);
+
+/* ---- a1: frame -> sample linear upsampler ------------------------------------------------- */
+/* replaces ddsp/core.py:7-21 `upsample(signal(B,Fr,C), factor)`; out (B, Fr*hop, C):
+ * out[t] = fma(1-a, x[t/hop], a*x[min(t/hop+1, Fr-1)]), a = (t%hop)/hop. */
+int ddsp_upsample(ddsp_ctx* ctx, void* stream, const float* x, int64_t B, int64_t Fr, int64_t C, int hop,
+                  float* out);
+
+/* ---- a1-a3: f0 frames -> wrapped rotation, frame phases, combtooth ------------------------- */
+#define DDSP_COMB_NONE 0
+#define DDSP_COMB_SINC 1        /* ddsp/vocoder.py:539  CombSub                                   */
+#define DDSP_COMB_SINC_GATED 2  /* ddsp/vocoder.py:459-460 CombSubFast: comb = 0 where f0 <= 0     */
+/* replaces upsample(f0) + fo_to_rot (ddsp/core.py:31-51) + `2*pi*rot[:, ::hop]` (ddsp/vocoder.py:515-517)
+ * + torch.sinc(sr*rot/(f0+1e-3)).  `precise` != 0 is the reference's infer=True (fp64 increments);
+ * 0 is infer=False (fp32 increments, fp64 running sum rounded to fp32 per sample).
+ * f0_frames (B,Fr); initial_phase (B,) radians or NULL; outputs (any may be NULL except phase_frames):
+ * rot (B,T) cycles in [-0.5,0.5]; phase (B,T) = 2*pi*rot (Sins, ddsp/vocoder.py:392); comb (B,T);
+ * f0_up (B,T) upsampled f0; phase_frames (B,Fr) radians. T = Fr*hop. */
+int ddsp_phase_scan(ddsp_ctx* ctx, void* stream, const float* f0_frames, const float* initial_phase, int64_t B,
+                    int64_t Fr, int hop, int sr, int precise, int comb_mode, float* rot, float* phase, float* comb,
+                    float* f0_up, float* phase_frames);
+
+/* ---- a5-a6: control frames -> linear-phase FIR frames -------------------------------------- */
+#define DDSP_FIR_ALLPASS 0  /* mags = exp(j*cumsum(pi*tanh(ctrl))), no window (ddsp/vocoder.py:521,540) */
+#define DDSP_FIR_DYNAMIC 1  /* mags = exp(ctrl), raised-cosine of half width 1.5*sr/(f0+1e-3) (:522,541-542; ddsp/core.py:292-303) */
+#define DDSP_FIR_STATIC 2   /* mags = exp(ctrl)/128, periodic Hann (:523,546; ddsp/core.py:242-289)  */
+/* replaces the ctrl activation + ddsp/core.py:306-328 `_frequency_impulse_response`.
+ * ctrl: (B*Fr) rows of `n_mag` values at row stride `ctrl_ld` (so a column block of the fused control
+ * matrix can be passed in place); f0_frames (B*Fr) (DYNAMIC only); ir out (B*Fr, n = 2*(n_mag-1)). */
+int ddsp_fir_from_ctrl(ddsp_ctx* ctx, void* stream, int mode, const float* ctrl, int64_t ctrl_ld, int n_mag,
+                       const float* f0_frames, int64_t rows, int sr, float* ir);
+
+/* ---- a7: frame-varying FIR (50%-overlap triangular cross-fade between frame filters) -------- */
+/* replaces ddsp/core.py:185-239 `_fft_convolve` (+ :147-182 crop): out[u] = sum over taps of
+ * x[t]*((1-j/hop)*ir[m] + (j/hop)*ir[min(m+1,Fr-1)])[u + n/2 - t], t = m*hop + j.
+ * excitation: DDSP_EXC_AUDIO      audio (B,T) is the input signal;
+ *             DDSP_EXC_UNIT_NOISE audio (B,T) holds U[0,1) draws and the input is 2*u-1 (the reference's
+ *                                 `torch.rand_like(x)*2-1`, ddsp/vocoder.py:545, with the draw injected);
+ *             DDSP_EXC_GENERATE   audio is NULL, the input is a counter-based U[-1,1) stream keyed by
+ *                                 noise_seed (perf mode: the CPU mt19937 stream cannot be reproduced on a GPU).
+ * out (B,T) or NULL receives the filtered signal; out_sum (B,T) or NULL receives filtered + add_in
+ * (fuses `harmonic + noise`, ddsp/vocoder.py:548); add_in and out_sum are given together.
+ * Requires hop == 512 and n even, 32 <= n <= 2046. */
+#define DDSP_EXC_AUDIO 0
+#define DDSP_EXC_UNIT_NOISE 1
+#define DDSP_EXC_GENERATE 2
+int ddsp_ltv_fir(ddsp_ctx* ctx, void* stream, const float* audio, int excitation, uint64_t noise_seed,
+                 const float* ir, int64_t B, int64_t Fr, int hop, int n, const float* add_in, float* out,
+                 float* out_sum);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDSP_AMD_H */

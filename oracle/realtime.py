@@ -1,0 +1,60 @@
+"""Oracle: caller-side glue around the synth call (TEST INFRASTRUCTURE, see oracle/__init__.py).
+
+CPU restatement of the SOLA splice of the real-time path (reference
+`gui.py:405-430`, windows `gui.py:349-351`), the offline slice cross-fade
+(`main.py:50-57`) and the volume gate (`main.py:111-116`, `gui.py:108-112`).
+No reference test or fixture covers these; pinned only by
+tests/golden/glue_*.npz generated from verbatim numpy/torch expressions in
+tests/golden/make_golden.py.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import dsp
+
+
+def fade_windows(xfade):
+    """ref: gui.py:349-351."""
+    fade_in = torch.sin(np.pi * torch.arange(0, 1, 1 / xfade) / 2) ** 2
+    return fade_in, 1 - fade_in
+
+
+def sola_step(audio, sola_buffer, block, xfade, search, delay):
+    """One block of the SOLA splice.  ref: gui.py:405-430.
+
+    audio :: (N,) model output for the sliding window; sola_buffer :: (xfade,)
+    tail kept from the previous block.  Returns (emitted (block,), new_buffer, shift).
+    """
+    tmp = audio[-block - xfade - search - delay: -delay].clone()
+    head = tmp[None, None, : xfade + search]
+    num = F.conv1d(head, sola_buffer[None, None, :])
+    den = torch.sqrt(F.conv1d(head ** 2, torch.ones(1, 1, xfade)) + 1e-8)
+    shift = int(torch.argmax(num[0, 0] / den[0, 0]))
+    tmp = tmp[shift: shift + block + xfade].clone()
+    fade_in, fade_out = fade_windows(xfade)
+    tmp[:xfade] = tmp[:xfade] * fade_in + sola_buffer * fade_out
+    return tmp[:-xfade], tmp[-xfade:].clone(), shift
+
+
+def slice_cross_fade(a, b, idx):
+    """ref: main.py:50-57 (numpy float64)."""
+    out = np.zeros(idx + b.shape[0])
+    fade = a.shape[0] - idx
+    out[:idx] = a[:idx]
+    k = np.linspace(0, 1.0, num=fade, endpoint=True)
+    out[idx:a.shape[0]] = (1 - k) * a[idx:] + k * b[:fade]
+    out[a.shape[0]:] = b[fade:]
+    return out
+
+
+def volume_gate(volume, threshold_db, hop):
+    """9-frame max-dilated gate, upsampled to sample rate.  ref: main.py:111-116.
+
+    volume :: (Fr,) numpy -> (1, Fr*hop) torch fp32.
+    """
+    m = (volume > 10 ** (float(threshold_db) / 20)).astype("float")
+    m = np.pad(m, (4, 4), constant_values=(m[0], m[-1]))
+    m = np.array([np.max(m[n: n + 9]) for n in range(len(m) - 8)])
+    m = torch.from_numpy(m).float()[None, :, None]
+    return dsp.frames_to_samples(m, hop).squeeze(-1)

@@ -1,0 +1,151 @@
+"""GPU parity of the DSP stage kernels (a1-a3, a5-a8) against the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rms
+from oracle import dsp as O
+
+pytestmark = pytest.mark.gpu
+
+SR, HOP = 44100, 512
+
+
+def _f0(seed, B, Fr, lo=65.0, hi=800.0):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy(rng.uniform(lo, hi, size=(B, Fr, 1)).astype(np.float32))
+
+
+@pytest.mark.parametrize("Fr,C", [(1, 1), (2, 3), (7, 32), (172, 1), (173, 5)])
+def test_upsample_bit_exact(ctx, dev, Fr, C):
+    rng = np.random.Generator(np.random.PCG64(11 + Fr))
+    x = torch.from_numpy(rng.standard_normal((3, Fr, C)).astype(np.float32) * 300)
+    want = O.frames_to_samples(x, HOP)
+    got = ctx.upsample(x.to(dev), HOP).cpu()
+    assert got.shape == want.shape
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("precise", [True, False])
+@pytest.mark.parametrize("with_init", [False, True])
+def test_phase_scan_matches_oracle(ctx, dev, precise, with_init):
+    B, Fr = 5, 172
+    f0f = _f0(3, B, Fr)
+    init = torch.tensor([0.3, -2.0, 3.1, 0.0, 6.0]) if with_init else None
+    f0 = O.frames_to_samples(f0f, HOP).squeeze(-1)
+    rot = O.rotation_from_f0(f0, SR, init, precise)
+    comb = O.sinc_comb(rot, f0, SR)
+    out = ctx.phase_scan(f0f.to(dev), HOP, SR, None if init is None else init.to(dev), precise, 1,
+                         want_rot=True, want_phase=True, want_f0=True)
+    assert torch.equal(out["f0_up"].cpu(), f0)
+    d = (out["rot"].cpu() - rot)
+    d = d - torch.round(d)                      # a wrap at +-0.5 is the same phase
+    # fp64 running sums differ only by summation order; in train mode a 1-ulp(fp32 of S) flip is possible
+    tol = 1e-6 if precise else 2.5e-4
+    assert d.abs().max() < tol
+    assert (d.abs() > 1e-6).float().mean() < 1e-4
+    pf = 2 * np.pi * rot[:, ::HOP]
+    dp = out["phase_frames"].cpu() - pf
+    assert (dp - 2 * np.pi * torch.round(dp / (2 * np.pi))).abs().max() < 2e-3
+    # combtooth: sin(pi*x)/(pi*x) with x up to ~340 -> compare where the wrap did not flip
+    same = d.abs() < 1e-7
+    dc = (out["comb"].cpu() - comb)[same]
+    assert dc.abs().max() < 2e-5
+    assert rms(out["comb"].cpu() - comb) < 1e-5
+
+
+def test_phase_scan_known_answers(ctx, dev):
+    """The reference's own known-answer tests (ddsp/core.py:62-97) with hop = 1 (sample-rate f0)."""
+    f = torch.tensor([[1.0, 1.0, 1.0]])
+    out = ctx.phase_scan(f.to(dev), 1, 4, None, False, 0, want_rot=True)["rot"].cpu()
+    assert torch.allclose(out, torch.tensor([[0.25, 0.50, -0.25]]))
+    f = torch.tensor([[1.0, 2.0, 3.0]])
+    out = ctx.phase_scan(f.to(dev), 1, 4, None, False, 0, want_rot=True)["rot"].cpu()
+    assert torch.allclose(out, torch.tensor([[0.25, -0.25, -0.50]]))
+    f = torch.tensor([[1.0, 1.0, 1.0]])
+    out = ctx.phase_scan(f.to(dev), 1, 4, torch.tensor([np.pi]).float().to(dev), False, 0, want_rot=True)["rot"].cpu()
+    assert torch.allclose(out, torch.tensor([[-0.25, 0.0, 0.25]]), atol=1e-6)
+    f = torch.tensor([[1.0, 1.0, 1.0], [1.0, 2.0, 3.0]])
+    ip = torch.tensor([np.pi, 0.0]).float()
+    out = ctx.phase_scan(f.to(dev), 1, 4, ip.to(dev), True, 0, want_rot=True)["rot"].cpu()
+    assert torch.allclose(out, torch.tensor([[-0.25, 0.0, 0.25], [0.25, -0.25, -0.50]]), atol=1e-5)
+
+
+def _ctrl(seed, B, Fr, W, std=0.5):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy((rng.standard_normal((B, Fr, W)) * std).astype(np.float32))
+
+
+def _resp(mode, c):
+    if mode == 0:
+        return torch.exp(1.j * torch.cumsum(np.pi * torch.tanh(c), dim=-1))
+    m = torch.exp(c) if mode == 1 else torch.exp(c) / 128
+    return torch.complex(m, torch.zeros_like(m))
+
+
+@pytest.mark.parametrize("mode,n_mag", [(0, 256), (1, 512), (2, 256), (1, 256), (2, 513), (0, 65)])
+def test_fir_from_ctrl(ctx, dev, mode, n_mag):
+    B, Fr = 3, 9
+    W = n_mag + 24
+    c = _ctrl(5 + mode, B, Fr, W)
+    f0f = _f0(9, B, Fr, 65.0, 800.0)
+    f0f[0, 0, 0] = 65.0      # half width 1017 > 511: plain raised cosine everywhere
+    f0f[0, 1, 0] = 800.0     # half width 82: the w>1 -> 1 quirk and the periodic w<-1 side both show
+    sub = c[..., 8:8 + n_mag]
+    hw = 1.5 * SR / (f0f + 1e-3) if mode == 1 else None
+    want = O.fir_from_response(_resp(mode, sub), hann=(mode != 0), half_width=hw)
+    got = ctx.fir_from_ctrl(mode, c.reshape(B * Fr, W).to(dev), 8, n_mag, B * Fr, SR,
+                            f0f.to(dev) if mode == 1 else None).cpu().reshape(B, Fr, -1)
+    assert got.shape == want.shape
+    scale = float(want.abs().max())
+    assert (got - want).abs().max() < 2e-5 * scale + 1e-7, (got - want).abs().max()
+    assert rms(got - want) < 2e-6 * scale
+
+
+@pytest.mark.parametrize("n,Fr,B", [(510, 6, 2), (1022, 6, 2), (510, 7, 1), (1022, 1, 2), (64, 3, 1), (2046, 5, 1)])
+def test_ltv_fir_small_vs_direct(ctx, dev, n, Fr, B):
+    rng = np.random.Generator(np.random.PCG64(n + Fr))
+    x = torch.from_numpy(rng.uniform(-1, 1, size=(B, Fr * HOP)).astype(np.float32))
+    ir = torch.from_numpy((rng.standard_normal((B, Fr, n)) / np.sqrt(n)).astype(np.float32))
+    want64 = O.ltv_fir_direct(x, ir)
+    want_fft = O.ltv_fir_fft(x, ir)
+    got, _ = ctx.ltv_fir(x.to(dev), ir.to(dev), B, Fr, HOP)
+    got = got.cpu()
+    assert rms(want_fft.double() - want64) < 1e-6           # the oracle's two forms agree
+    assert rms(got.double() - want64) < 1e-6
+    assert (got.double() - want64).abs().max() < 1e-5
+
+
+def test_ltv_fir_full_size_and_fusions(ctx, dev):
+    B, Fr, n = 4, 172, 1022
+    rng = np.random.Generator(np.random.PCG64(77))
+    u = torch.from_numpy(rng.random((B, Fr * HOP), dtype=np.float32))
+    ir = torch.from_numpy((rng.standard_normal((B, Fr, n)) / np.sqrt(n)).astype(np.float32))
+    add = torch.from_numpy(rng.standard_normal((B, Fr * HOP)).astype(np.float32))
+    want = O.ltv_fir_fft(u * 2 - 1, ir)
+    got, got_sum = ctx.ltv_fir(u.to(dev), ir.to(dev), B, Fr, HOP, excitation=1, add_in=add.to(dev))
+    assert rms(got.cpu() - want) < 1e-6
+    assert torch.equal(got_sum.cpu(), add + got.cpu())
+    # linearity: filter(a*x) == a*filter(x) exactly for a power of two
+    got2, _ = ctx.ltv_fir((u * 2 - 1).mul(0.5).to(dev), ir.to(dev), B, Fr, HOP)
+    assert torch.equal(got2.cpu() * 2, got.cpu())
+    # in-kernel excitation: deterministic per seed, different across seeds, U[-1,1)-like after an identity filter
+    ident = torch.zeros(1, 4, 64)
+    ident[:, :, 32] = 1.0
+    g1, _ = ctx.ltv_fir(None, ident.to(dev), 1, 4, HOP, excitation=2, noise_seed=123)
+    g2, _ = ctx.ltv_fir(None, ident.to(dev), 1, 4, HOP, excitation=2, noise_seed=123)
+    g3, _ = ctx.ltv_fir(None, ident.to(dev), 1, 4, HOP, excitation=2, noise_seed=124)
+    assert torch.equal(g1, g2) and not torch.equal(g1, g3)
+    g = g1.cpu()
+    assert g.min() >= -1 and g.max() < 1 and abs(float(g.mean())) < 0.05 and abs(float(g.var()) - 1 / 3) < 0.03
+
+
+def test_argument_errors(ctx, dev):
+    x = torch.zeros(1, 2 * HOP, device=dev)
+    ir = torch.zeros(1, 2, 511, device=dev)
+    with pytest.raises(ValueError):
+        ctx.ltv_fir(x, ir, 1, 2, HOP)                         # odd filter length
+    with pytest.raises(ValueError):
+        ctx.ltv_fir(x, torch.zeros(1, 2, 510, device=dev), 1, 2, 256)   # hop not built
+    with pytest.raises(RuntimeError):
+        ctx.upsample(torch.zeros(1, 2, 1), HOP)               # CPU tensor: no fallback
