@@ -47,6 +47,8 @@ SIGNATURES = {
     "ddsp_upsample": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _int, _vp]),
     "ddsp_phase_scan": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "ddsp_fir_from_ctrl": (_int, [_vp, _vp, _int, _vp, _i64, _int, _vp, _i64, _int, _vp]),
+    "ddsp_unit2ctrl_fwd": (_int, [_vp, _vp, _c.POINTER(U2CWeights), _vp, _vp, _vp, _vp, _vp, _i64,
+                                  _c.POINTER(_i64), _c.POINTER(_f32), _int, _i64, _i64, _vp]),
     "ddsp_ltv_fir": (_int, [_vp, _vp, _vp, _int, _u64, _vp, _i64, _i64, _int, _int, _vp, _vp, _vp]),
 }
 
@@ -149,6 +151,30 @@ class Context:
         self.call("ddsp_phase_scan", _ptr(f0), _ptr(ip), B, Fr, int(hop), int(sr), 1 if precise else 0,
                   int(comb_mode), _ptr(rot), _ptr(phase), _ptr(comb), _ptr(f0_up), _ptr(pf))
         return {"rot": rot, "phase": phase, "comb": comb, "f0_up": f0_up, "phase_frames": pf}
+
+    # -- a4 ------------------------------------------------------------------------------------
+    def unit2ctrl(self, weights, units, f0_frames, phase_frames, volume, spk_id, spk_mix_dict, n_out):
+        B, Fr, _ = units.shape
+        dev = units.device
+        units = units.contiguous().float()
+        f0 = f0_frames.reshape(B, Fr).contiguous().float()
+        ph = phase_frames.reshape(B, Fr).contiguous().float()
+        vol = volume.reshape(B, Fr).contiguous().float()
+        ctrl = torch.empty(B, Fr, n_out, device=dev, dtype=torch.float32)
+        if spk_mix_dict is not None:
+            n_mix = len(spk_mix_dict)
+            ids = (_i64 * max(n_mix, 1))(*[int(k) for k in spk_mix_dict.keys()])
+            ws = (_f32 * max(n_mix, 1))(*[float(v) for v in spk_mix_dict.values()])
+            sid, n_sid = None, 0
+        else:
+            n_mix, ids, ws = 0, None, None
+            sid = spk_id.reshape(-1).to(device=dev, dtype=torch.int64).contiguous()
+            n_sid = sid.numel()
+            if n_sid not in (1, B):
+                raise ValueError(f"spk_id must hold 1 or B={B} ids, got {n_sid}")
+        self.call("ddsp_unit2ctrl_fwd", ctypes.byref(weights), _ptr(units), _ptr(f0), _ptr(ph), _ptr(vol), _ptr(sid),
+                  n_sid, ids, ws, n_mix, B, Fr, _ptr(ctrl))
+        return ctrl
 
     # -- a5-a6 ---------------------------------------------------------------------------------
     def fir_from_ctrl(self, mode, ctrl2d, col0, n_mag, rows, sr, f0_frames=None):

@@ -87,6 +87,39 @@ int ddsp_ltv_fir(ddsp_ctx* ctx, void* stream, const float* audio, int excitation
                  const float* ir, int64_t B, int64_t Fr, int hop, int n, const float* add_in, float* out,
                  float* out_sum);
 
+
+/* ---- a4: unit -> control network ---------------------------------------------------------- */
+/* Device pointers into the model's state dict (reference key names), fp32, dense.
+ * Shapes: conv weights (Cout, Cin, k) as torch stores them; Linear weights (out, in); d = 256.
+ *   prenet_conv1_w (256, n_unit, 3)  prenet_gn_* (256)  prenet_conv2_w (256, 256, 3)
+ *   f0_w/phase_w/volume_w (256, 1) + biases (256)        spk_table (n_spk, 256)
+ *   per layer l0..l2: norm_* (256); q/k/v_w (512, 256) + b (512); proj (266, 64); out_w (256, 512) + b (256);
+ *                     cm_ln_* (256); cm_pw1_w (1024, 256, 1); cm_dw_w (512, 1, 31); cm_pw2_w (256, 512, 1)
+ *   final_ln_* (256); head_g (n_out, 1); head_v (n_out, 256); head_b (n_out)                               */
+typedef struct ddsp_u2c_layer {
+    const float *norm_w, *norm_b, *q_w, *q_b, *k_w, *k_b, *v_w, *v_b, *proj, *out_w, *out_b;
+    const float *cm_ln_w, *cm_ln_b, *cm_pw1_w, *cm_pw1_b, *cm_dw_w, *cm_dw_b, *cm_pw2_w, *cm_pw2_b;
+} ddsp_u2c_layer;
+
+typedef struct ddsp_u2c_weights {
+    const float *prenet_conv1_w, *prenet_conv1_b, *prenet_gn_w, *prenet_gn_b, *prenet_conv2_w, *prenet_conv2_b;
+    const float *f0_w, *f0_b, *phase_w, *phase_b, *volume_w, *volume_b, *spk_table;
+    int n_spk, n_unit, n_out;
+    ddsp_u2c_layer layer[3];
+    const float *final_ln_w, *final_ln_b, *head_g, *head_v, *head_b;
+} ddsp_u2c_weights;
+
+/* replaces ddsp/unit2control.py:68-101 `Unit2Control.forward` + ddsp/pcmer.py (non-causal, c=False only).
+ * units (B,Fr,n_unit); f0_frames, phase_frames, volume (B,Fr); spk_id (n_spk_id) int64, 1-based, n_spk_id in
+ * {1, B} (the reference broadcasts a (1,1) id); speaker mixing (`spk_mix_dict`): n_mix > 0 host arrays
+ * mix_ids_host (1-based) / mix_w_host replace spk_id (n_mix <= 16).  ctrl out (B,Fr,n_out), the fused
+ * control matrix that `split_to_dict` (ddsp/unit2control.py:10-20) views.  The `weights` struct itself is a
+ * HOST pointer. */
+int ddsp_unit2ctrl_fwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_weights* weights_host, const float* units,
+                       const float* f0_frames, const float* phase_frames, const float* volume,
+                       const int64_t* spk_id, int64_t n_spk_id, const int64_t* mix_ids_host,
+                       const float* mix_w_host, int n_mix, int64_t B, int64_t Fr, float* ctrl);
+
 #ifdef __cplusplus
 }
 #endif

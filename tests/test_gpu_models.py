@@ -1,0 +1,112 @@
+"""GPU parity of the control network (a4) and of the full model forwards (a12) through the drop-in classes.
+
+Gate (BASELINE.json north_star): waveform within 1e-4 RMS of the reference PyTorch CPU path on identical
+f0 / units / volume / spk_id inputs (noise draw injected)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synthetic
+from conftest import GOLDEN, rms
+from oracle import ctrlnet as OC
+from oracle import synth as OS
+
+pytestmark = pytest.mark.gpu
+HOP = 512
+GATE = 1e-4
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    return {k: (torch.from_numpy(z[k]) if z[k].ndim else z[k].item()) for k in z.files}
+
+
+def _to(d, dev):
+    return {k: v.to(dev) for k, v in d.items()}
+
+
+@pytest.mark.parametrize("B,Fr", [(2, 12), (3, 172), (1, 87)])
+@pytest.mark.parametrize("spk_mode", ["per_row", "broadcast", "mix"])
+def test_unit2ctrl_matches_oracle(dev, lib_path, B, Fr, spk_mode):
+    model, cfg = synthetic.build_model("CombSub", seed=99)
+    sd = {k[len("unit2ctrl."):]: v for k, v in model.state_dict().items() if k.startswith("unit2ctrl.")}
+    inp = synthetic.make_inputs(1234 + B, B, Fr, with_noise=False)
+    phase = torch.from_numpy(np.random.Generator(np.random.PCG64(5)).uniform(-np.pi, np.pi, (B, Fr)).astype(np.float32))
+    spk = inp["spk_id"] if spk_mode == "per_row" else inp["spk_id"][:1]
+    mix = {3: 0.5, 10: 0.2, 99: 0.3} if spk_mode == "mix" else None
+    with torch.no_grad():
+        want = OC.unit2control(sd, inp["units"], inp["f0"], phase, inp["volume"], spk, mix,
+                               model.unit2ctrl.output_splits, return_flat=True)
+    model = model.to(dev)
+    got = model.unit2ctrl.forward_flat(inp["units"].to(dev), inp["f0"].to(dev), phase.to(dev), inp["volume"].to(dev),
+                                       spk.to(dev), mix).cpu()
+    assert got.shape == want.shape
+    err = (got - want).abs().max()
+    assert err < 2e-4, err               # ctrl ~ N(0, 0.6^2); fp32 chains of depth 256..768
+    assert rms(got - want) < 2e-5
+    d = model.unit2ctrl(inp["units"].to(dev), inp["f0"].to(dev), phase.to(dev), inp["volume"].to(dev), spk.to(dev), mix)
+    assert list(d.keys()) == ["group_delay", "harmonic_magnitude", "noise_magnitude"]
+    assert [v.shape[-1] for v in d.values()] == [256, 512, 256]
+
+
+CASES = [("infer", dict(infer=True)), ("train", dict(infer=False)),
+         ("mix", dict(infer=True, spk_mix_dict={1: 0.25, 7: 0.75})),
+         ("init", dict(infer=True, initial_phase=torch.tensor([1.0, -2.0])))]
+
+
+def test_combsub_against_reference_golden(dev, lib_path):
+    """Fixture produced by the reference's own CombSub.forward (tests/golden/make_golden.py, tier B)."""
+    g = load("model_CombSub.npz")
+    model, cfg = synthetic.build_model("CombSub", seed=g["seed_weights"], device=dev)
+    inp = _to(synthetic.make_inputs(g["seed_inputs"], 2, 12), dev)
+    for tag, kw in CASES:
+        kw = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in kw.items()}
+        with torch.no_grad():
+            sig, ph, (hm, nz) = model(inp["units"], inp["f0"], inp["volume"], inp["spk_id"], noise=inp["noise"], **kw)
+        assert sig.shape == (2, 12 * HOP) and ph.shape == (2, 12, 1)
+        if kw["infer"]:
+            assert rms(sig.cpu() - g[f"signal_{tag}"]) < GATE, (tag, rms(sig.cpu() - g[f"signal_{tag}"]))
+            assert rms(hm.cpu() - g[f"harmonic_{tag}"]) < GATE
+        assert rms(nz.cpu() - g[f"noise_{tag}"]) < GATE
+        dp = (ph.cpu() - g[f"phase_{tag}"]) / (2 * np.pi)
+        assert (dp - torch.round(dp)).abs().max() < (1e-6 if kw["infer"] else 2.5e-4)
+
+
+@pytest.mark.parametrize("B,Fr,infer", [(4, 172, True), (2, 173, True), (2, 87, False)])
+def test_combsub_against_oracle(dev, lib_path, B, Fr, infer):
+    model, cfg = synthetic.build_model("CombSub", seed=7)
+    sd = model.state_dict()
+    inp = synthetic.make_inputs(4242 + Fr, B, Fr)
+    with torch.no_grad():
+        sig_o, ph_o, (hm_o, nz_o), aux = OS.combsub_forward(sd, cfg, inp["units"], inp["f0"], inp["volume"],
+                                                            inp["spk_id"], infer=infer, noise=inp["noise"])
+    model = model.to(dev)
+    d = _to(inp, dev)
+    with torch.no_grad():
+        sig, ph, (hm, nz) = model(d["units"], d["f0"], d["volume"], d["spk_id"], infer=infer, noise=d["noise"])
+    assert rms(nz.cpu() - nz_o) < GATE
+    if infer:
+        assert rms(hm.cpu() - hm_o) < GATE, rms(hm.cpu() - hm_o)
+        assert rms(sig.cpu() - sig_o) < GATE, rms(sig.cpu() - sig_o)
+    else:
+        # train mode rounds the running phase to fp32 per sample: a different (equally valid) summation order
+        # may flip single roundings by one fp32 ulp of the running sum (1.2e-4 cycles at S~1600), SURVEY 0.5
+        assert rms(sig.cpu() - sig_o) < 5e-3
+    # returned signal is a fresh writable tensor (callers multiply a mask in place, main.py:159)
+    sig *= 0.5
+    # in-kernel noise path: repeatable under torch.manual_seed, finite, and harmonic part unchanged
+    torch.manual_seed(3)
+    s1, _, (h1, n1) = model(d["units"], d["f0"], d["volume"], d["spk_id"], infer=infer)
+    torch.manual_seed(3)
+    s2, _, (h2, n2) = model(d["units"], d["f0"], d["volume"], d["spk_id"], infer=infer)
+    assert torch.equal(s1, s2) and torch.equal(h1, hm) and torch.isfinite(s1).all()
+    assert 0.5 < rms(n1) / rms(nz) < 2.0
+
+
+def test_no_cpu_fallback(lib_path):
+    model, cfg = synthetic.build_model("CombSub", seed=7)
+    inp = synthetic.make_inputs(1, 1, 4)
+    with pytest.raises(RuntimeError):
+        model(inp["units"], inp["f0"], inp["volume"], inp["spk_id"])
