@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""Throughput bench of the hot path: CombSub 44.1 kHz synthesis, batch = 64 x 2 s clips per GPU
+(BASELINE.json configs[1]), units/f0/volume/spk_id -> rendered audio, inputs resident in HBM.
+
+    python bench.py [--gpus N --steps K --warmup W]                      # N = 1
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one full forward (`CombSub.forward`) over the per-GPU batch.  With N > 1 utterances are sharded
+over the ranks (weak scaling: 64 per GPU) and the rendered audio is all-gathered over RCCL/xGMI on a side
+stream, overlapped with the next step's compute (the gather of the last step is inside the timed region).
+Rank 0 prints ONE JSON line; `roofline` is measured live with HIP events around the dominant kernel,
+`cpu_baseline` times the CPU oracle (a port of the reference's PyTorch CPU path) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "ddsp-svc-official_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+B_PER_GPU = 64
+FRAMES = 172
+HOP = 512
+SR = 44100
+BYTES_PER_SAMPLE_API = 6.02   # units 256*4 + f0 4 + volume 4 in, 512*4 + 4 out per frame
+PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+DOMINANT = "u2c_gemm_linear"          # kernel family with the largest share of the step (profiles/)
+DOMINANT_KERNEL = "gemm::kernel<...,A_PLAIN> (fp32 MFMA 32x32x2), Linear / 1x1-conv layers of unit2ctrl"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="CombSub", choices=["CombSub", "Sins256", "CombSubFast"])
+    return ap.parse_args()
+
+
+def cpu_baseline(seed):
+    """Times the oracle's CombSub forward on the host cores: B=8 clips of 2 s, median of 3 (about 10-30 s)."""
+    import synthetic
+    from oracle import synth as OS
+    # the GPU box gives one GPU's job a 16-core share; more threads than that only oversubscribes ATen's pools
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, avail)))
+    Bc = 8
+    model, cfg = synthetic.build_model("CombSub", seed=seed)
+    sd = model.state_dict()
+    inp = synthetic.make_inputs(seed + 1, Bc, FRAMES)
+    times = []
+    with torch.no_grad():
+        OS.combsub_forward(sd, cfg, inp["units"], inp["f0"], inp["volume"], inp["spk_id"], noise=inp["noise"])
+        for _ in range(3):
+            t0 = time.perf_counter()
+            OS.combsub_forward(sd, cfg, inp["units"], inp["f0"], inp["volume"], inp["spk_id"], noise=inp["noise"])
+            times.append(time.perf_counter() - t0)
+    t = sorted(times)[1]
+    return {"value": Bc * FRAMES * HOP / t, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle CombSub.forward, B={Bc} x 2 s clips, median of 3 ({t * 1e3:.0f} ms each)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the synthesis path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import hipddsp
+    import synthetic
+    import sharding
+
+    seed = synthetic.BASE_SEED + 2
+    model, cfg = synthetic.build_model(args.model, seed=seed, device=dev)
+    inp = synthetic.make_inputs(seed + 100 + rank, B_PER_GPU, FRAMES, with_noise=False)
+    inp = {k: v.to(dev) for k, v in inp.items()}
+    T = FRAMES * HOP
+    ctx = hipddsp.context_for(dev)
+
+    gather = sharding.AudioGather(world, B_PER_GPU, T, dev) if world > 1 else None
+
+    def step(i):
+        with torch.no_grad():
+            sig, _, _ = model(inp["units"], inp["f0"], inp["volume"], inp["spk_id"], noise_seed=1000 + i)
+        if gather is not None:
+            gather.submit(sig)
+        return sig
+
+    for i in range(args.warmup):
+        step(i)
+    if gather is not None:
+        gather.wait()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ctx.profile_begin([DOMINANT])          # HIP events around the dominant kernel only (a few per step)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    if gather is not None:
+        gather.wait()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dom = ctx.profile_end()[DOMINANT]
+    if dist is not None:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    total_samples = world * B_PER_GPU * T * args.steps
+    value = total_samples / dt
+    out = {
+        "metric": "audio samples/sec @44.1kHz CombSub synth" if args.model == "CombSub" else f"audio samples/sec @44.1kHz {args.model} synth",
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.model} 44.1 kHz, batch={B_PER_GPU}x2 s per GPU (Fr={FRAMES}, T={T}), "
+                               "units/f0/volume/spk_id -> audio, seeded random weights, in-kernel noise",
+                   "sharding": "utterances over ranks; all_gather of rendered audio overlapped on a side stream"
+                   if world > 1 else "single GPU"},
+        "x_realtime": value / SR,
+        "hbm_frac_api_bytes": value * BYTES_PER_SAMPLE_API / 8e12,
+    }
+    # untimed breakdown pass: every kernel family bracketed by events (adds launch gaps, so not part of `value`)
+    ctx.profile_begin()
+    nb = 3
+    for i in range(nb):
+        step(10_000 + i)
+    if gather is not None:
+        gather.wait()
+    torch.cuda.synchronize()
+    fam = ctx.profile_end()
+    if rank == 0:
+        avg_ms = dom["ms_total"] / dom["launches"]
+        achieved = dom["flops_total"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
+        out["roofline"] = {"kernel": DOMINANT_KERNEL, "bound": "mfma", "achieved": achieved,
+                           "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F32_TFLOPS,
+                           "traffic": None, "avg_launch_ms": avg_ms, "launches": dom["launches"],
+                           "algorithmic_flops_per_launch": dom["flops_total"] / dom["launches"]}
+        out["kernel_families_ms_per_step"] = {k: round(v["ms_total"] / nb, 4) for k, v in fam.items()}
+        out["kernel_families_tflops"] = {k: round(v["flops_total"] / (v["ms_total"] * 1e-3) / 1e12, 2)
+                                         for k, v in fam.items() if v["flops_total"] > 0}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(seed)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -18,8 +18,27 @@ struct ddsp_table {
     size_t bytes;
 };
 
+// kernel families for the built-in HIP-event profiler (ddsp_profile_begin / _end)
+enum {
+    PF_PHASE_SCAN = 0, PF_FIR_ACT, PF_FIR_DFT_GEMM, PF_LTV_FIR, PF_U2C_PREP, PF_U2C_GEMM_CONV3, PF_U2C_GEMM_LINEAR,
+    PF_U2C_GEMM_FEAT, PF_U2C_GEMM_CTX, PF_U2C_GEMM_ATTNOUT, PF_U2C_ROWWISE, PF_SINS_BANK, PF_SPECTRAL_OLA,
+    PF_RSS_LOSS, PF_SOLA, PF_UPSAMPLE, PF_OTHER, PF_COUNT
+};
+
+struct ddsp_prof_rec {
+    hipEvent_t start, stop;
+    int id;
+    double flops, bytes;
+};
+#define DDSP_PROF_CAP 16384
+
 struct ddsp_ctx {
     int device;
+    // profiler
+    uint64_t prof_mask;
+    ddsp_prof_rec* prof;
+    int prof_n, prof_events_made;
+    int prof_open;
     char err[512];
     // bump-allocated scratch, grown on demand between calls (never inside a captured region)
     char* scratch;
@@ -60,6 +79,10 @@ int ddsp_scratch_get(ddsp_ctx* ctx, size_t bytes, void** out);
 int ddsp_scratch_reserve_bytes(ddsp_ctx* ctx, size_t bytes);
 // tables (tables.hip)
 int ddsp_get_table(ddsp_ctx* ctx, hipStream_t st, int kind, int n0, int n1, float** out);
+
+// profiler hooks (ctx.hip): bracket ONE kernel launch (or a tight group) on `st` when the family is enabled
+void ddsp_prof_begin(ddsp_ctx* ctx, hipStream_t st, int id);
+void ddsp_prof_end(ddsp_ctx* ctx, hipStream_t st, double flops, double bytes);
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -32,6 +32,13 @@ extern "C" int ddsp_ctx_destroy(ddsp_ctx* ctx) {
     (void)hipDeviceSynchronize();
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->packed) (void)hipFree(ctx->packed);
+    if (ctx->prof) {
+        for (int i = 0; i < ctx->prof_events_made; ++i) {
+            (void)hipEventDestroy(ctx->prof[i].start);
+            (void)hipEventDestroy(ctx->prof[i].stop);
+        }
+        free(ctx->prof);
+    }
     for (int i = 0; i < ctx->n_tables; ++i)
         if (ctx->tables[i].dev) (void)hipFree(ctx->tables[i].dev);
     free(ctx);
@@ -73,5 +80,71 @@ int ddsp_scratch_get(ddsp_ctx* ctx, size_t bytes, void** out) {
         return ddsp_fail(ctx, DDSP_ERR_OOM, "scratch arena too small", "internal sizing error");
     *out = ctx->scratch + off;
     ctx->scratch_used = off + bytes;
+    return DDSP_OK;
+}
+
+// ---- HIP-event profiler ------------------------------------------------------------------------------
+static const char* kFamilyName[PF_COUNT] = {
+    "phase_scan", "fir_act", "fir_dft_gemm", "ltv_fir", "u2c_prep", "u2c_gemm_conv3", "u2c_gemm_linear",
+    "u2c_gemm_feat", "u2c_gemm_ctx", "u2c_gemm_attnout", "u2c_rowwise", "sins_bank", "spectral_ola", "rss_loss",
+    "sola", "upsample", "other"};
+
+void ddsp_prof_begin(ddsp_ctx* ctx, hipStream_t st, int id) {
+    ctx->prof_open = 0;
+    if (!ctx->prof_mask || !((ctx->prof_mask >> id) & 1ull) || ctx->prof_n >= DDSP_PROF_CAP) return;
+    if (!ctx->prof) ctx->prof = (ddsp_prof_rec*)calloc(DDSP_PROF_CAP, sizeof(ddsp_prof_rec));
+    if (!ctx->prof) return;
+    ddsp_prof_rec& r = ctx->prof[ctx->prof_n];
+    if (ctx->prof_n >= ctx->prof_events_made) {
+        if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+        ctx->prof_events_made = ctx->prof_n + 1;
+    }
+    r.id = id;
+    if (hipEventRecord(r.start, st) != hipSuccess) return;
+    ctx->prof_open = 1;
+}
+
+void ddsp_prof_end(ddsp_ctx* ctx, hipStream_t st, double flops, double bytes) {
+    if (!ctx->prof_open) return;
+    ddsp_prof_rec& r = ctx->prof[ctx->prof_n];
+    r.flops = flops;
+    r.bytes = bytes;
+    if (hipEventRecord(r.stop, st) == hipSuccess) ctx->prof_n++;
+    ctx->prof_open = 0;
+}
+
+extern "C" int ddsp_profile_begin(ddsp_ctx* ctx, uint64_t family_mask) {
+    if (!ctx) return DDSP_ERR_ARG;
+    ctx->prof_n = 0;
+    ctx->prof_open = 0;
+    ctx->prof_mask = family_mask;
+    return DDSP_OK;
+}
+
+extern "C" int ddsp_profile_end(ddsp_ctx* ctx, ddsp_prof_entry* out, int max_entries, int* n_entries) {
+    if (!ctx || !out || !n_entries) return DDSP_ERR_ARG;
+    ctx->prof_mask = 0;
+    ddsp_prof_entry agg[PF_COUNT];
+    memset(agg, 0, sizeof(agg));
+    for (int i = 0; i < ctx->prof_n; ++i) {
+        ddsp_prof_rec& r = ctx->prof[i];
+        DDSP_HIP(ctx, hipEventSynchronize(r.stop));
+        float ms = 0.f;
+        DDSP_HIP(ctx, hipEventElapsedTime(&ms, r.start, r.stop));
+        ddsp_prof_entry& a = agg[r.id];
+        a.launches += 1;
+        a.ms_total += ms;
+        a.flops_total += r.flops;
+        a.bytes_total += r.bytes;
+    }
+    int n = 0;
+    for (int id = 0; id < PF_COUNT && n < max_entries; ++id) {
+        if (!agg[id].launches) continue;
+        agg[id].family = id;
+        strncpy(agg[id].name, kFamilyName[id], sizeof(agg[id].name) - 1);
+        out[n++] = agg[id];
+    }
+    *n_entries = n;
+    ctx->prof_n = 0;
     return DDSP_OK;
 }

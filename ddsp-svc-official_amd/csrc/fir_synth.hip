@@ -89,9 +89,12 @@ extern "C" int ddsp_fir_from_ctrl(ddsp_ctx* ctx, void* stream, int mode, const f
     rc = ddsp_get_table(ctx, st, kind, M, 0, &tab);
     if (rc) return rc;
 
+    ddsp_prof_begin(ctx, st, PF_FIR_ACT);
     hipLaunchKernelGGL(fir_act_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, mode, ctrl, ctrl_ld, M,
                        lda, rows, act);
+    ddsp_prof_end(ctx, st, 0.0, 4.0 * rows * (M + K));
     DDSP_LAUNCH_CHECK(ctx);
+    ddsp_prof_begin(ctx, st, PF_FIR_DFT_GEMM);
 
     gemm::Args g = gemm::make(act, lda, tab, ddsp_pad4(n), (int)rows, n, K);
     if (mode == DDSP_FIR_DYNAMIC) {
@@ -101,6 +104,7 @@ extern "C" int ddsp_fir_from_ctrl(ddsp_ctx* ctx, void* stream, int mode, const f
         gemm::EpiStore epi{ir, n, nullptr, 1, 0, 0};
         gemm::launch<true, false, gemm::A_PLAIN>(st, g, 1, epi);
     }
+    ddsp_prof_end(ctx, st, 2.0 * rows * (double)n * K, 4.0 * rows * (K + n));
     DDSP_LAUNCH_CHECK(ctx);
     return DDSP_OK;
 }

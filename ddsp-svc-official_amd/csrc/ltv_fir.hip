@@ -204,7 +204,16 @@ extern "C" int ddsp_ltv_fir(ddsp_ctx* ctx, void* stream, const float* audio, int
         attr_set = true;
     }
     dim3 grid((unsigned)((Fr + SEG - 1) / SEG), (unsigned)B);
+    ddsp_prof_begin(ctx, (hipStream_t)stream, PF_LTV_FIR);
     hipLaunchKernelGGL(ltv_fir_kernel, grid, dim3(64 * 2 * SEG), lds_bytes, (hipStream_t)stream, g);
+    // algorithmic work: every input sample meets two frame filters of n taps (2 FLOP per tap);
+    // algorithmic bytes: x in (0 when generated), filters in, y out (+ add_in, + second output)
+    {
+        const double T = (double)Fr * HOP, nb = (double)B;
+        const double flops = nb * T * n * 2.0 * 2.0;
+        const double bytes = 4.0 * nb * (T * ((audio ? 1 : 0) + (out ? 1 : 0) + (out_sum ? 2 : 0)) + (double)Fr * n);
+        ddsp_prof_end(ctx, (hipStream_t)stream, flops, bytes);
+    }
     DDSP_LAUNCH_CHECK(ctx);
     return DDSP_OK;
 }

@@ -217,6 +217,7 @@ extern "C" int ddsp_phase_scan(ddsp_ctx* ctx, void* stream, const float* f0_fram
     const float scale = (float)Fr / (float)(Fr * hop);
     const unsigned blocks = (unsigned)ceil_div64(nf, WAVES_PER_BLOCK);
     ScanOut o{rot, phase, comb, f0_up, phase_frames};
+    ddsp_prof_begin(ctx, st, PF_PHASE_SCAN);
     if (precise) {
         hipLaunchKernelGGL(frame_sum_kernel<true>, dim3(blocks), dim3(256), 0, st, f0_frames, nf, (int)Fr, hop, scale,
                            sr, fsum);
@@ -227,6 +228,10 @@ extern "C" int ddsp_phase_scan(ddsp_ctx* ctx, void* stream, const float* f0_fram
                            sr, fsum);
         hipLaunchKernelGGL(frame_scan_kernel<false>, dim3(blocks), dim3(256), 0, st, f0_frames, fsum, initial_phase,
                            nf, (int)Fr, hop, scale, sr, comb_mode, o);
+    }
+    {
+        const double outs = (rot ? 1 : 0) + (phase ? 1 : 0) + (comb ? 1 : 0) + (f0_up ? 1 : 0);
+        ddsp_prof_end(ctx, st, 0.0, 4.0 * nf * (2.0 + outs * hop));
     }
     DDSP_LAUNCH_CHECK(ctx);
     return DDSP_OK;

@@ -1,0 +1,80 @@
+// a10: additive sinusoid bank  s[t] = sum_k lerp_t(A_k) * sin(k * phase[t]),  k = 1..H.
+//
+// Replaces ddsp/vocoder.py:397,402-412 (exp/128, remove_above_fmax, chunked upsample*sin sum) and
+// ddsp/core.py:24-28.  The reference materialises (B,T,32) amplitude and phase tensors per chunk (721 MB
+// each at B=64); here one workgroup renders one frame (hop samples): the two bracketing amplitude frames
+// are activated once into LDS (2*H floats), every lane owns hop/256 samples, and the harmonics are walked
+// with a complex rotation recurrence z_k = z_{k-1} * z_1 that is re-seeded from an accurate sincosf every
+// 32 harmonics, so the cost per (sample, harmonic) is 7 VALU ops instead of a full sinf.
+// Bound: fp32 vector ALU (H*7 FLOP per sample vs 4*H/hop + 8 B per sample of HBM traffic).
+#include "common.h"
+
+namespace {
+
+constexpr int RESEED = 32;
+
+__global__ void __launch_bounds__(256) sins_bank_kernel(const float* __restrict__ ctrl, int64_t ld, int H,
+                                                        const float* __restrict__ f0_frames,
+                                                        const float* __restrict__ phase, int Fr, int hop, float fmax,
+                                                        float* __restrict__ out) {
+    extern __shared__ float amp[];  // [2][H]: activated amplitudes of frame m and m+1 (clamped)
+    const int m = blockIdx.x, b = blockIdx.y;
+    const int64_t row = (int64_t)b * Fr + m;
+    const int m1 = (m + 1 < Fr) ? 1 : 0;
+    for (int i = threadIdx.x; i < 2 * H; i += blockDim.x) {
+        const int which = i / H, k = i % H;
+        const int64_t r = row + (which ? m1 : 0);
+        const float a = __fdiv_rn(expf(ctrl[r * ld + k]), 128.0f);
+        // remove_above_fmax: (k*f0 < fmax) + 1e-7, all in fp32
+        const float pk = __fmul_rn(f0_frames[r], (float)(k + 1));
+        const float aa = __fadd_rn(pk < fmax ? 1.0f : 0.0f, 1e-7f);
+        amp[i] = __fmul_rn(a, aa);
+    }
+    __syncthreads();
+    const float* a0 = amp;
+    const float* a1 = amp + H;
+    const float inv_hop = 1.0f / (float)hop;  // hop is a power of two: exact
+    for (int j = threadIdx.x; j < hop; j += blockDim.x) {
+        const int64_t t = row * hop + j;
+        const float ph = phase[t];
+        const float w1 = (float)j * inv_hop, w0 = 1.0f - w1;
+        float s1, c1;
+        sincosf(ph, &s1, &c1);
+        float acc = 0.f;
+        for (int k0 = 0; k0 < H; k0 += RESEED) {
+            // seed at harmonic k0+1 with the reference's own argument rounding: sin(fp32((k0+1) * ph))
+            float zs, zc;
+            sincosf(__fmul_rn(ph, (float)(k0 + 1)), &zs, &zc);
+            const int kend = (k0 + RESEED < H) ? k0 + RESEED : H;
+            for (int k = k0; k < kend; ++k) {
+                const float a = fmaf(w0, a0[k], __fmul_rn(w1, a1[k]));  // same rounding as the upsampler
+                acc = fmaf(a, zs, acc);
+                const float nc = fmaf(zc, c1, -zs * s1);
+                const float ns = fmaf(zs, c1, zc * s1);
+                zc = nc;
+                zs = ns;
+            }
+        }
+        out[t] = acc;
+    }
+}
+
+}  // namespace
+
+extern "C" int ddsp_sins_bank(ddsp_ctx* ctx, void* stream, const float* ctrl, int64_t ctrl_ld, int n_harmonics,
+                              const float* f0_frames, const float* phase, int64_t B, int64_t Fr, int hop, int sr,
+                              float* out) {
+    DDSP_REQUIRE(ctx, ctx && ctrl && f0_frames && phase && out, "ddsp_sins_bank: null argument");
+    DDSP_REQUIRE(ctx, n_harmonics >= 1 && n_harmonics <= 4096 && ctrl_ld >= n_harmonics, "ddsp_sins_bank: bad harmonics");
+    DDSP_REQUIRE(ctx, B >= 0 && B <= 65535 && Fr >= 1 && hop >= 1 && (hop & (hop - 1)) == 0, "ddsp_sins_bank: bad shape (hop must be a power of two)");
+    if (B == 0) return DDSP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    ddsp_prof_begin(ctx, st, PF_SINS_BANK);
+    hipLaunchKernelGGL(sins_bank_kernel, dim3((unsigned)Fr, (unsigned)B), dim3(256), 2 * n_harmonics * sizeof(float), st,
+                       ctrl, ctrl_ld, n_harmonics, f0_frames, phase, (int)Fr, hop, (float)sr / 2.0f, out);
+    ddsp_prof_end(ctx, st, 7.0 * B * Fr * hop * (double)n_harmonics,
+                  4.0 * B * Fr * ((double)n_harmonics + 1 + 2.0 * hop));
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}

@@ -251,32 +251,43 @@ __global__ void __launch_bounds__(256) glu_kernel(const float* __restrict__ g1, 
     }
 }
 
-// depthwise Conv1d(k=31, pad 15, groups=512) over frames + SiLU; weight (512,1,31)
+// depthwise Conv1d(k=31, pad 15, groups=512) over frames + SiLU; weight (512,1,31).
+// One thread owns one channel for a run of DW_RUN consecutive frames of one utterance: its 31 taps and a
+// sliding window of DW_RUN+30 inputs stay in registers (2.9 loads per output instead of 31); lanes walk
+// channels, so every load/store of a wavefront is one contiguous 256-B row segment.
+constexpr int DW_RUN = 16;
 __global__ void __launch_bounds__(256) dwconv_silu_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          const float* __restrict__ bias, int64_t rows, int Fr,
+                                                          const float* __restrict__ bias, int B, int Fr,
                                                           float* __restrict__ out) {
-    // thread = (frame m, 4 channels); consecutive threads walk channels -> coalesced 16 B loads per tap
-    const int64_t total = rows * (INNER / 4);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t m = i / (INNER / 4);
-        const int c4 = (int)(i % (INNER / 4)) * 4;
-        const int f = (int)(m % Fr);
-        f32x4 acc = *(const f32x4*)(bias + c4);
+    const int c = blockIdx.x * 256 + threadIdx.x;       // channel (INNER = 512 -> 2 blocks in x)
+    const int runs = (Fr + DW_RUN - 1) / DW_RUN;
+    const int b = blockIdx.y / runs, f0 = (blockIdx.y % runs) * DW_RUN;
+    float wt[DWK];
 #pragma unroll
-        for (int t = 0; t < DWK; ++t) {
-            const int ff = f + t - DWK / 2;
-            if (ff >= 0 && ff < Fr) {
-                const f32x4 v = *(const f32x4*)(x + (m + t - DWK / 2) * INNER + c4);
+    for (int t = 0; t < DWK; ++t) wt[t] = w[c * DWK + t];
+    const float* xb = x + ((int64_t)b * Fr) * INNER + c;
+    float win[DW_RUN + DWK - 1];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = fmaf(w[(c4 + j) * DWK + t], v[j], acc[j]);
-            }
-        }
-        f32x4 o;
+    for (int i = 0; i < DW_RUN + DWK - 1; ++i) {
+        const int f = f0 + i - DWK / 2;
+        win[i] = (f >= 0 && f < Fr) ? xb[(int64_t)f * INNER] : 0.f;
+    }
+    const float bi = bias[c];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = acc[j] * (1.0f / (1.0f + expf(-acc[j])));
-        *(f32x4*)(out + m * INNER + c4) = o;
+    for (int o = 0; o < DW_RUN; ++o) {
+        float acc = bi;
+#pragma unroll
+        for (int t = 0; t < DWK; ++t) acc = fmaf(wt[t], win[o + t], acc);
+        if (f0 + o < Fr) out[((int64_t)b * Fr + f0 + o) * INNER + c] = acc * (1.0f / (1.0f + expf(-acc)));
     }
 }
+
+#define PROF(id, flops, bytes, ...)              \
+    do {                                          \
+        ddsp_prof_begin(ctx, st, id);             \
+        __VA_ARGS__;                              \
+        ddsp_prof_end(ctx, st, (double)(flops), (double)(bytes)); \
+    } while (0)
 
 inline unsigned grid_for(int64_t total, int per_block = 256, int cap = 8192) {
     int64_t g = (total + per_block - 1) / per_block;
@@ -341,9 +352,10 @@ extern "C" int ddsp_unit2ctrl_fwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
     float* dw = k;
 
     // ---- weight preparation ----
-    hipLaunchKernelGGL(pack_conv3_kernel, dim3(grid_for(n_w1)), dim3(256), 0, st, w.prenet_conv1_w, D, w.n_unit, w1);
-    hipLaunchKernelGGL(pack_conv3_kernel, dim3(grid_for(n_w2)), dim3(256), 0, st, w.prenet_conv2_w, D, D, w2);
-    hipLaunchKernelGGL(weight_norm_kernel, dim3((w.n_out + 3) / 4), dim3(256), 0, st, w.head_g, w.head_v, w.n_out, D, wh);
+    PROF(PF_U2C_PREP, 0, 8.0 * (n_w1 + n_w2 + n_wh),
+         hipLaunchKernelGGL(pack_conv3_kernel, dim3(grid_for(n_w1)), dim3(256), 0, st, w.prenet_conv1_w, D, w.n_unit, w1);
+         hipLaunchKernelGGL(pack_conv3_kernel, dim3(grid_for(n_w2)), dim3(256), 0, st, w.prenet_conv2_w, D, D, w2);
+         hipLaunchKernelGGL(weight_norm_kernel, dim3((w.n_out + 3) / 4), dim3(256), 0, st, w.head_g, w.head_v, w.n_out, D, wh));
 
     // ---- prenet: conv k3 -> GroupNorm(4) -> LeakyReLU -> conv k3 ----
     {
@@ -351,17 +363,20 @@ extern "C" int ddsp_unit2ctrl_fwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
         g.Fr = (int)Fr;
         g.Cin = w.n_unit;
         gemm::EpiStore e{t1, D, w.prenet_conv1_b, 1, 0, 0};
-        gemm::launch<true, true, gemm::A_CONV3>(st, g, 1, e);
+        PROF(PF_U2C_GEMM_CONV3, 2.0 * M * D * 3 * w.n_unit, 4.0 * M * (w.n_unit + D),
+             (gemm::launch<true, true, gemm::A_CONV3>(st, g, 1, e)));
     }
-    hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(4, (unsigned)B), dim3(256), 0, st, t1, (int)Fr, gst);
-    hipLaunchKernelGGL(groupnorm_lrelu_kernel, dim3(grid_for(M * (D / 4))), dim3(256), 0, st, t1, gst, w.prenet_gn_w,
-                       w.prenet_gn_b, M, (int)Fr, t2);
+    PROF(PF_U2C_ROWWISE, 0, 4.0 * M * D,
+         hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(4, (unsigned)B), dim3(256), 0, st, t1, (int)Fr, gst));
+    PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
+         hipLaunchKernelGGL(groupnorm_lrelu_kernel, dim3(grid_for(M * (D / 4))), dim3(256), 0, st, t1, gst,
+                            w.prenet_gn_w, w.prenet_gn_b, M, (int)Fr, t2));
     {
         gemm::Args g = gemm::make(t2, D, w2, 3 * D, iM, D, 3 * D);
         g.Fr = (int)Fr;
         g.Cin = D;
         gemm::EpiStore e{x, D, w.prenet_conv2_b, 1, 0, 0};
-        gemm::launch<true, true, gemm::A_CONV3>(st, g, 1, e);
+        PROF(PF_U2C_GEMM_CONV3, 2.0 * M * D * 3 * D, 8.0 * M * D, (gemm::launch<true, true, gemm::A_CONV3>(st, g, 1, e)));
     }
     MixArgs mix;
     mix.n = n_mix;
@@ -369,34 +384,42 @@ extern "C" int ddsp_unit2ctrl_fwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
         mix.ids[i] = mix_ids_host[i];
         mix.w[i] = mix_w_host[i];
     }
-    hipLaunchKernelGGL(embed_add_kernel, dim3(grid_for(M * D)), dim3(256), 0, st, x, f0_frames, phase_frames, volume, w,
-                       spk_id, n_spk_id, mix, M, (int)Fr);
+    PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
+         hipLaunchKernelGGL(embed_add_kernel, dim3(grid_for(M * D)), dim3(256), 0, st, x, f0_frames, phase_frames, volume,
+                            w, spk_id, n_spk_id, mix, M, (int)Fr));
     DDSP_LAUNCH_CHECK(ctx);
 
     const unsigned rows_g = (unsigned)ceil_div64(M, 4), rows8_g = (unsigned)ceil_div64(M8, 4);
     for (int l = 0; l < 3; ++l) {
         const ddsp_u2c_layer& L = w.layer[l];
         // -- x += to_out(linear_attention(LN(x)))
-        hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, x, L.norm_w, L.norm_b, M, y);
+        PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
+             hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, x, L.norm_w, L.norm_b, M, y));
         const float* pw[3] = {L.q_w, L.k_w, L.v_w};
         const float* pb[3] = {L.q_b, L.k_b, L.v_b};
         float* po[3] = {q, k, v};
         for (int i = 0; i < 3; ++i) {
             gemm::Args g = gemm::make(y, D, pw[i], D, iM, INNER, D);
             gemm::EpiStore e{po[i], INNER, pb[i], 1, 0, 0};
-            gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e);
+            PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * INNER * D, 4.0 * M * (D + INNER),
+                 (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
         }
         {   // random-feature projections: (M*8, 64) x (266, 64)^T
             gemm::Args g = gemm::make(q, DH, L.proj, DH, (int)M8, NF, DH);
             gemm::EpiStore e{qf, LDF, nullptr, 1, 0, 0};
-            gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e);
+            PROF(PF_U2C_GEMM_FEAT, 2.0 * M8 * NF * DH, 4.0 * M8 * (DH + NF),
+                 (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
             g.A = k;
             e.C = kf;
-            gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e);
+            PROF(PF_U2C_GEMM_FEAT, 2.0 * M8 * NF * DH, 4.0 * M8 * (DH + NF),
+                 (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
         }
-        hipLaunchKernelGGL(feature_map_kernel<true>, dim3(rows8_g), dim3(256), 0, st, qf, q, M8);
-        hipLaunchKernelGGL(feature_map_kernel<false>, dim3(rows8_g), dim3(256), 0, st, kf, k, M8);
-        hipLaunchKernelGGL(key_sum_kernel, dim3((unsigned)(B * H)), dim3(320), 0, st, kf, (int)Fr, ks);
+        PROF(PF_U2C_ROWWISE, 0, 4.0 * M8 * (2 * NF + DH),
+             hipLaunchKernelGGL(feature_map_kernel<true>, dim3(rows8_g), dim3(256), 0, st, qf, q, M8));
+        PROF(PF_U2C_ROWWISE, 0, 4.0 * M8 * (2 * NF + DH),
+             hipLaunchKernelGGL(feature_map_kernel<false>, dim3(rows8_g), dim3(256), 0, st, kf, k, M8));
+        PROF(PF_U2C_ROWWISE, 0, 4.0 * M8 * NF,
+             hipLaunchKernelGGL(key_sum_kernel, dim3((unsigned)(B * H)), dim3(320), 0, st, kf, (int)Fr, ks));
         {   // ctx[b,h] (266 x 64) = k'^T v : A stored [n][j] (K x M), B stored [n][e] (K x N)
             gemm::Args g = gemm::make(kf, (int64_t)H * LDF, v, INNER, NF, DH, (int)Fr);
             g.zdiv = H;
@@ -405,9 +428,11 @@ extern "C" int ddsp_unit2ctrl_fwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
             g.sB_hi = (int64_t)Fr * INNER;
             g.sB_lo = DH;
             gemm::EpiStore e{cx, DH, nullptr, 1, (int64_t)NF * DH, 0};
-            gemm::launch_tile<64, 64, false, false, gemm::A_PLAIN>(st, g, (int)(B * H), e);
+            PROF(PF_U2C_GEMM_CTX, 2.0 * M8 * NF * DH, 4.0 * M8 * (NF + DH),
+                 (gemm::launch_tile<64, 64, false, false, gemm::A_PLAIN>(st, g, (int)(B * H), e)));
         }
-        hipLaunchKernelGGL(attn_denominator_kernel, dim3(rows8_g), dim3(256), 0, st, qf, ks, (int)Fr, M8, dinv);
+        PROF(PF_U2C_ROWWISE, 0, 4.0 * M8 * NF,
+             hipLaunchKernelGGL(attn_denominator_kernel, dim3(rows8_g), dim3(256), 0, st, qf, ks, (int)Fr, M8, dinv));
         {   // out[b,n,h,:] = dinv * (q'[b,n,h,:] ctx[b,h])
             gemm::Args g = gemm::make(qf, (int64_t)H * LDF, cx, DH, (int)Fr, DH, NF);
             g.zdiv = H;
@@ -416,36 +441,45 @@ extern "C" int ddsp_unit2ctrl_fwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
             g.sB_hi = (int64_t)H * NF * DH;
             g.sB_lo = (int64_t)NF * DH;
             EpiAttnOut e{attn, dinv, (int)Fr};
-            gemm::launch_tile<64, 64, true, false, gemm::A_PLAIN>(st, g, (int)(B * H), e);
+            PROF(PF_U2C_GEMM_ATTNOUT, 2.0 * M8 * NF * DH, 4.0 * M8 * (NF + DH),
+                 (gemm::launch_tile<64, 64, true, false, gemm::A_PLAIN>(st, g, (int)(B * H), e)));
         }
         {
             gemm::Args g = gemm::make(attn, INNER, L.out_w, INNER, iM, D, INNER);
             gemm::EpiResidual e{x, x, D, L.out_b};
-            gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e);
+            PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * D * INNER, 4.0 * M * (INNER + 2 * D),
+                 (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
         }
         // -- x += conv_module(x)
-        hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, x, L.cm_ln_w, L.cm_ln_b, M, y);
+        PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
+             hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, x, L.cm_ln_w, L.cm_ln_b, M, y));
         {
             gemm::Args g = gemm::make(y, D, L.cm_pw1_w, D, iM, 2 * INNER, D);
             gemm::EpiStore e{g1, 2 * INNER, L.cm_pw1_b, 1, 0, 0};
-            gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e);
+            PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * 2 * INNER * D, 4.0 * M * (D + 2 * INNER),
+                 (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
         }
-        hipLaunchKernelGGL(glu_kernel, dim3(grid_for(M * (INNER / 4))), dim3(256), 0, st, g1, M, glu);
-        hipLaunchKernelGGL(dwconv_silu_kernel, dim3(grid_for(M * (INNER / 4))), dim3(256), 0, st, glu, L.cm_dw_w,
-                           L.cm_dw_b, M, (int)Fr, dw);
+        PROF(PF_U2C_ROWWISE, 0, 12.0 * M * INNER,
+             hipLaunchKernelGGL(glu_kernel, dim3(grid_for(M * (INNER / 4))), dim3(256), 0, st, g1, M, glu));
+        PROF(PF_U2C_ROWWISE, 2.0 * M * INNER * DWK, 8.0 * M * INNER,
+             hipLaunchKernelGGL(dwconv_silu_kernel, dim3(INNER / 256, (unsigned)(B * ((Fr + DW_RUN - 1) / DW_RUN))),
+                                dim3(256), 0, st, glu, L.cm_dw_w, L.cm_dw_b, (int)B, (int)Fr, dw));
         {
             gemm::Args g = gemm::make(dw, INNER, L.cm_pw2_w, INNER, iM, D, INNER);
             gemm::EpiResidual e{x, x, D, L.cm_pw2_b};
-            gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e);
+            PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * D * INNER, 4.0 * M * (INNER + 2 * D),
+                 (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
         }
         DDSP_LAUNCH_CHECK(ctx);
     }
     // ---- LayerNorm -> weight-normed head ----
-    hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, x, w.final_ln_w, w.final_ln_b, M, y);
+    PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
+         hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, x, w.final_ln_w, w.final_ln_b, M, y));
     {
         gemm::Args g = gemm::make(y, D, wh, D, iM, w.n_out, D);
         gemm::EpiStore e{ctrl, w.n_out, w.head_b, 1, 0, 0};
-        gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e);
+        PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * w.n_out * D, 4.0 * M * (D + w.n_out),
+             (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
     }
     DDSP_LAUNCH_CHECK(ctx);
     return DDSP_OK;

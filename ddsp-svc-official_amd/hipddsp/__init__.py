@@ -37,6 +37,16 @@ class U2CWeights(_c.Structure):
     )
 
 
+class ProfEntry(_c.Structure):
+    """Mirror of `ddsp_prof_entry`."""
+    _fields_ = [("family", _int), ("name", _c.c_char * 36), ("launches", _i64), ("ms_total", _c.c_double),
+                ("flops_total", _c.c_double), ("bytes_total", _c.c_double)]
+
+
+FAMILIES = ["phase_scan", "fir_act", "fir_dft_gemm", "ltv_fir", "u2c_prep", "u2c_gemm_conv3", "u2c_gemm_linear",
+            "u2c_gemm_feat", "u2c_gemm_ctx", "u2c_gemm_attnout", "u2c_rowwise", "sins_bank", "spectral_ola", "rss_loss",
+            "sola", "upsample", "other"]
+
 # name -> (restype, argtypes); every symbol declared in include/ddsp_amd.h must be listed here
 SIGNATURES = {
     "ddsp_abi_version": (_int, []),
@@ -47,6 +57,12 @@ SIGNATURES = {
     "ddsp_upsample": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _int, _vp]),
     "ddsp_phase_scan": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "ddsp_fir_from_ctrl": (_int, [_vp, _vp, _int, _vp, _i64, _int, _vp, _i64, _int, _vp]),
+    "ddsp_sins_bank": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp, _i64, _i64, _int, _int, _vp]),
+    "ddsp_spectral_ola": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _int, _u64, _i64, _i64, _int, _vp]),
+    "ddsp_sola": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp]),
+    "ddsp_volume_gate": (_int, [_vp, _vp, _vp, _vp, _f32, _i64, _i64, _int]),
+    "ddsp_profile_begin": (_int, [_vp, _u64]),
+    "ddsp_profile_end": (_int, [_vp, _c.POINTER(ProfEntry), _int, _c.POINTER(_int)]),
     "ddsp_unit2ctrl_fwd": (_int, [_vp, _vp, _c.POINTER(U2CWeights), _vp, _vp, _vp, _vp, _vp, _i64,
                                   _c.POINTER(_i64), _c.POINTER(_f32), _int, _i64, _i64, _vp]),
     "ddsp_ltv_fir": (_int, [_vp, _vp, _vp, _int, _u64, _vp, _i64, _i64, _int, _int, _vp, _vp, _vp]),
@@ -126,6 +142,23 @@ class Context:
         rc = getattr(self.lib, name)(self.handle, self._stream(), *args)
         self._check(rc, name)
 
+    # -- measurement ---------------------------------------------------------------------------
+    def profile_begin(self, families=None):
+        """Arms HIP-event timing for the named kernel families (all when None)."""
+        mask = 0
+        for f in (families if families is not None else FAMILIES):
+            mask |= 1 << FAMILIES.index(f)
+        self._check(self.lib.ddsp_profile_begin(self.handle, mask), "ddsp_profile_begin")
+
+    def profile_end(self):
+        """-> {family: {launches, ms_total, flops_total, bytes_total}} (waits for the recorded events)."""
+        buf = (ProfEntry * 32)()
+        n = _int(0)
+        self._check(self.lib.ddsp_profile_end(self.handle, buf, 32, ctypes.byref(n)), "ddsp_profile_end")
+        return {buf[i].name.decode(): {"launches": buf[i].launches, "ms_total": buf[i].ms_total,
+                                       "flops_total": buf[i].flops_total, "bytes_total": buf[i].bytes_total}
+                for i in range(n.value)}
+
     # -- a1 ------------------------------------------------------------------------------------
     def upsample(self, x, hop):
         B, Fr, C = x.shape
@@ -197,6 +230,41 @@ class Context:
         self.call("ddsp_ltv_fir", _ptr(audio), int(excitation), int(noise_seed), _ptr(ir), B, Fr, int(hop), int(n),
                   _ptr(add_in), _ptr(out), _ptr(out_sum))
         return out, out_sum
+
+
+    # -- a10 -----------------------------------------------------------------------------------
+    def sins_bank(self, ctrl2d, col0, n_harmonics, f0_frames, phase, B, Fr, hop, sr):
+        out = torch.empty(B, Fr * hop, device=ctrl2d.device, dtype=torch.float32)
+        f0 = f0_frames.reshape(-1).contiguous().float()
+        self.call("ddsp_sins_bank", _ptr(ctrl2d) + 4 * col0, ctrl2d.shape[-1], int(n_harmonics), _ptr(f0), _ptr(phase),
+                  B, Fr, int(hop), int(sr), _ptr(out))
+        return out
+
+    # -- a11 -----------------------------------------------------------------------------------
+    def spectral_ola(self, ctrl2d, comb, noise, excitation, noise_seed, B, Fr, hop):
+        out = torch.empty(B, Fr * hop, device=ctrl2d.device, dtype=torch.float32)
+        self.call("ddsp_spectral_ola", _ptr(ctrl2d), ctrl2d.shape[-1], _ptr(comb), _ptr(noise), int(excitation),
+                  int(noise_seed), B, Fr, int(hop), _ptr(out))
+        return out
+
+    # -- a14 -----------------------------------------------------------------------------------
+    def sola(self, audio, sola_buffer, block, xfade, search, delay):
+        """audio (N,), sola_buffer (xfade,) updated in place -> (emitted (block,), shift int32 device tensor)."""
+        audio = audio.contiguous().float()
+        emitted = torch.empty(block, device=audio.device, dtype=torch.float32)
+        shift = torch.empty(1, device=audio.device, dtype=torch.int32)
+        self.call("ddsp_sola", _ptr(audio), audio.numel(), int(block), int(xfade), int(search), int(delay),
+                  _ptr(sola_buffer), _ptr(emitted), _ptr(shift))
+        return emitted, shift
+
+    # -- a15 -----------------------------------------------------------------------------------
+    def volume_gate_(self, signal, volume, threshold_db, hop):
+        """In place: signal (B,T) *= upsample(dilate9(volume > 10^(dB/20)))."""
+        B, T = signal.shape
+        vol = volume.reshape(B, -1).contiguous().float()
+        self.call("ddsp_volume_gate", _ptr(signal), _ptr(vol), float(10 ** (float(threshold_db) / 20)), B,
+                  vol.shape[1], int(hop))
+        return signal
 
 
 _contexts = {}

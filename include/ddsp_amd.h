@@ -120,6 +120,53 @@ int ddsp_unit2ctrl_fwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_weights* weig
                        const int64_t* spk_id, int64_t n_spk_id, const int64_t* mix_ids_host,
                        const float* mix_w_host, int n_mix, int64_t B, int64_t Fr, float* ctrl);
 
+/* ---- a10: additive sinusoid bank ----------------------------------------------------------- */
+/* replaces ddsp/vocoder.py:397,402-412 + ddsp/core.py:24-28: amplitudes exp(ctrl)/128 masked by
+ * ((k*f0 < sr/2) + 1e-7), upsampled per harmonic, times sin(k*phase), summed over k = 1..n_harmonics.
+ * ctrl rows (B*Fr) at stride ctrl_ld; f0_frames (B*Fr); phase (B,T) radians as produced by
+ * ddsp_phase_scan; out (B,T).  hop must be a power of two. */
+int ddsp_sins_bank(ddsp_ctx* ctx, void* stream, const float* ctrl, int64_t ctrl_ld, int n_harmonics,
+                   const float* f0_frames, const float* phase, int64_t B, int64_t Fr, int hop, int sr, float* out);
+
+/* ---- a11: CombSubFast windowed spectral overlap-add ------------------------------------------ */
+/* replaces ddsp/vocoder.py:462-490.  ctrl rows (B*Fr) at stride ctrl_ld hold
+ * [harmonic_magnitude 513 | harmonic_phase 513 | noise_magnitude 513]; comb (B,T) from ddsp_phase_scan
+ * (DDSP_COMB_SINC_GATED); noise (B,T) U[0,1) draws with excitation DDSP_EXC_UNIT_NOISE, or NULL with
+ * DDSP_EXC_GENERATE + noise_seed; out (B,T).  hop == 512 (1024-point frames). */
+int ddsp_spectral_ola(ddsp_ctx* ctx, void* stream, const float* ctrl, int64_t ctrl_ld, const float* comb,
+                      const float* noise, int excitation, uint64_t noise_seed, int64_t B, int64_t Fr, int hop,
+                      float* out);
+
+/* ---- a14: SOLA splice of the real-time path -------------------------------------------------- */
+/* replaces gui.py:405-430: within audio[-block-xfade-search-delay : -delay] find the lag (0..search) that
+ * maximises the energy-normalised correlation with sola_buffer (xfade,), cross-fade (sin^2 windows,
+ * gui.py:349-351) the head with sola_buffer, emit `block` samples, and keep the next xfade samples in
+ * sola_buffer (updated in place).  shift: device int32 (no host sync). */
+int ddsp_sola(ddsp_ctx* ctx, void* stream, const float* audio, int64_t n_audio, int block, int xfade, int search,
+              int delay, float* sola_buffer, float* emitted, int* shift);
+
+/* ---- a15: volume gate ------------------------------------------------------------------------ */
+/* replaces main.py:111-116,159 / gui.py:108-112,127: signal (B,T) *= upsample(dilate9(volume > threshold)),
+ * in place (threshold = 10^(dB/20), linear); volume (B,Fr). */
+int ddsp_volume_gate(ddsp_ctx* ctx, void* stream, float* signal, const float* volume, float threshold, int64_t B,
+                     int64_t Fr, int hop);
+
+/* ---- measurement: per-kernel-family HIP-event timing on the launch stream --------------------- */
+/* ddsp_profile_begin arms the families in `family_mask` (bit i = family i, see the name returned); while armed,
+ * each kernel launch of such a family is bracketed by hipEventRecord on the caller's stream.  ddsp_profile_end
+ * disarms, waits for the events and returns one aggregated entry per family that launched: launches, summed
+ * duration, and the ALGORITHMIC flops / HBM bytes the library attributes to those launches. */
+typedef struct ddsp_prof_entry {
+    int family;
+    char name[36];
+    int64_t launches;
+    double ms_total;
+    double flops_total;
+    double bytes_total;
+} ddsp_prof_entry;
+int ddsp_profile_begin(ddsp_ctx* ctx, uint64_t family_mask);
+int ddsp_profile_end(ddsp_ctx* ctx, ddsp_prof_entry* out, int max_entries, int* n_entries);
+
 #ifdef __cplusplus
 }
 #endif

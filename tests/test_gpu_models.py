@@ -110,3 +110,68 @@ def test_no_cpu_fallback(lib_path):
     inp = synthetic.make_inputs(1, 1, 4)
     with pytest.raises(RuntimeError):
         model(inp["units"], inp["f0"], inp["volume"], inp["spk_id"])
+
+
+# ---- Sins and CombSubFast ------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["Sins", "CombSubFast"])
+def test_other_models_against_reference_golden(dev, lib_path, name):
+    g = load(f"model_{name}.npz")
+    model, cfg = synthetic.build_model(name, seed=g["seed_weights"], device=dev)
+    inp = synthetic.make_inputs(g["seed_inputs"], 2, 12)
+    if name == "Sins":
+        inp["f0"][0, 3, 0] = 700.0
+    inp = _to(inp, dev)
+    for tag, kw in CASES:
+        kw = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in kw.items()}
+        with torch.no_grad():
+            sig, ph, (hm, nz) = model(inp["units"], inp["f0"], inp["volume"], inp["spk_id"], noise=inp["noise"], **kw)
+        assert sig.shape == (2, 12 * HOP)
+        if name == "Sins":
+            assert ph.shape == (2, 12 * HOP, 1)           # sample-rate phase (reference vocoder.py:423)
+            ph = ph[:, ::HOP]
+        else:
+            assert ph.shape == (2, 12, 1) and hm is sig and nz is sig    # same tensor three times (:492)
+        dp = (ph.cpu() - g[f"phase_{tag}"]) / (2 * np.pi)
+        assert (dp - torch.round(dp)).abs().max() < (1e-6 if kw["infer"] else 2.5e-4)
+        if kw["infer"]:
+            err = rms(sig.cpu() - g[f"signal_{tag}"])
+            assert err < GATE, (name, tag, err)
+            if name == "Sins":
+                assert rms(hm.cpu() - g[f"harmonic_{tag}"]) < GATE and rms(nz.cpu() - g[f"noise_{tag}"]) < GATE
+
+
+@pytest.mark.parametrize("name,B,Fr", [("Sins", 3, 172), ("Sins256", 2, 87), ("CombSubFast", 3, 172),
+                                       ("CombSubFast", 2, 173)])
+def test_other_models_against_oracle(dev, lib_path, name, B, Fr):
+    model, cfg = synthetic.build_model(name, seed=21)
+    sd = model.state_dict()
+    inp = synthetic.make_inputs(777 + Fr, B, Fr)
+    with torch.no_grad():
+        sig_o, ph_o, _, aux = OS.FORWARD[cfg["type"]](sd, cfg, inp["units"], inp["f0"], inp["volume"], inp["spk_id"],
+                                                      noise=inp["noise"])
+    model = model.to(dev)
+    d = _to(inp, dev)
+    with torch.no_grad():
+        sig, ph, _ = model(d["units"], d["f0"], d["volume"], d["spk_id"], noise=d["noise"])
+    err = rms(sig.cpu() - sig_o)
+    assert err < GATE, (name, err, rms(sig_o))
+    torch.manual_seed(1)
+    s1 = model(d["units"], d["f0"], d["volume"], d["spk_id"])[0]
+    torch.manual_seed(1)
+    s2 = model(d["units"], d["f0"], d["volume"], d["spk_id"])[0]
+    assert torch.equal(s1, s2) and torch.isfinite(s1).all()
+
+
+def test_sins_bank_stage(ctx, dev):
+    """Bank alone (BASELINE config #3 'additive-only', H=256) against the oracle, incl. harmonics crossing sr/2."""
+    from oracle import dsp as O
+    B, Fr, H = 2, 40, 256
+    rng = np.random.Generator(np.random.PCG64(8))
+    ctrl = torch.from_numpy((rng.standard_normal((B, Fr, H + 8)) * 0.5).astype(np.float32))
+    f0f = torch.from_numpy(rng.uniform(65, 800, (B, Fr, 1)).astype(np.float32))
+    f0 = O.frames_to_samples(f0f, HOP).squeeze(-1)
+    phase = 2 * np.pi * O.rotation_from_f0(f0, 44100, None, True)
+    amps = O.mask_above_nyquist(torch.exp(ctrl[..., 4:4 + H]) / 128, f0f, 44100 / 2)
+    want = O.harmonic_bank(amps, phase, HOP)
+    got = ctx.sins_bank(ctrl.reshape(B * Fr, -1).to(dev), 4, H, f0f.to(dev), phase.to(dev), B, Fr, HOP, 44100).cpu()
+    assert rms(got - want) < 2e-6 and (got - want).abs().max() < 2e-5, rms(got - want)
