@@ -22,6 +22,8 @@
 #pragma once
 #include "common.h"
 
+#include <type_traits>
+
 namespace gemm {
 
 enum { A_PLAIN = 0, A_CONV3 = 1 };
@@ -39,6 +41,14 @@ struct Args {
 };
 
 constexpr int BK = 32;
+// global 16-byte loads at dword alignment (rows of a signal framed at an arbitrary length N start anywhere)
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+
+// An epilogue that declares `static constexpr bool kPair = true` is called as epi(z, m, n, v, v_of_column_n^1).
+template <class E, class = void>
+struct epi_wants_pair : std::false_type {};
+template <class E>
+struct epi_wants_pair<E, std::void_t<decltype(E::kPair)>> : std::true_type {};
 
 template <int BM, int BN, bool A_KC, bool B_KC, int A_MODE, class Epi>
 __global__ void __launch_bounds__(256) kernel(Args g, Epi epi) {
@@ -77,12 +87,12 @@ __global__ void __launch_bounds__(256) kernel(Args g, Epi epi) {
                         if (k < g.K) {
                             const int tap = k / g.Cin, c = k - tap * g.Cin;
                             const int f = m % g.Fr + tap - 1;
-                            if (f >= 0 && f < g.Fr) v = *(const f32x4*)(A + (int64_t)(m + tap - 1) * g.lda + c);
+                            if (f >= 0 && f < g.Fr) v = *(const f32x4_u*)(A + (int64_t)(m + tap - 1) * g.lda + c);
                         }
                     } else {
                         const float* p = A + (int64_t)m * g.lda + k;
                         if (k + 3 < g.K) {
-                            v = *(const f32x4*)p;
+                            v = *(const f32x4_u*)p;
                         } else {
                             if (k < g.K) v[0] = p[0];
                             if (k + 1 < g.K) v[1] = p[1];
@@ -96,7 +106,7 @@ __global__ void __launch_bounds__(256) kernel(Args g, Epi epi) {
                 if (k < g.K) {
                     const float* p = A + (int64_t)k * g.lda + m;
                     if (m + 3 < g.M) {
-                        v = *(const f32x4*)p;
+                        v = *(const f32x4_u*)p;
                     } else {
                         if (m < g.M) v[0] = p[0];
                         if (m + 1 < g.M) v[1] = p[1];
@@ -116,7 +126,7 @@ __global__ void __launch_bounds__(256) kernel(Args g, Epi epi) {
                 if (n < g.N) {
                     const float* p = B + (int64_t)n * g.ldb + k;
                     if (k + 3 < g.K) {
-                        v = *(const f32x4*)p;
+                        v = *(const f32x4_u*)p;
                     } else {
                         if (k < g.K) v[0] = p[0];
                         if (k + 1 < g.K) v[1] = p[1];
@@ -129,7 +139,7 @@ __global__ void __launch_bounds__(256) kernel(Args g, Epi epi) {
                 if (k < g.K) {
                     const float* p = B + (int64_t)k * g.ldb + n;
                     if (n + 3 < g.N) {
-                        v = *(const f32x4*)p;
+                        v = *(const f32x4_u*)p;
                     } else {
                         if (n < g.N) v[0] = p[0];
                         if (n + 1 < g.N) v[1] = p[1];
@@ -216,7 +226,13 @@ __global__ void __launch_bounds__(256) kernel(Args g, Epi epi) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < g.M && n < g.N) epi(z, m, n, acc[i][j][r]);
+                if constexpr (epi_wants_pair<Epi>::value) {
+                    // columns (2f, 2f+1) sit on adjacent lanes: hand each lane its neighbour's value too
+                    const float other = __shfl_xor(acc[i][j][r], 1, 64);
+                    if (m < g.M && n < g.N) epi(z, m, n, acc[i][j][r], other);
+                } else {
+                    if (m < g.M && n < g.N) epi(z, m, n, acc[i][j][r]);
+                }
             }
         }
 }

@@ -59,6 +59,7 @@ SIGNATURES = {
     "ddsp_fir_from_ctrl": (_int, [_vp, _vp, _int, _vp, _i64, _int, _vp, _i64, _int, _vp]),
     "ddsp_sins_bank": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp, _i64, _i64, _int, _int, _vp]),
     "ddsp_spectral_ola": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _int, _u64, _i64, _i64, _int, _vp]),
+    "ddsp_rss_loss": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _c.POINTER(_int), _int, _f32, _f32, _vp, _vp]),
     "ddsp_sola": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp]),
     "ddsp_volume_gate": (_int, [_vp, _vp, _vp, _vp, _f32, _i64, _i64, _int]),
     "ddsp_profile_begin": (_int, [_vp, _u64]),
@@ -246,6 +247,23 @@ class Context:
         self.call("ddsp_spectral_ola", _ptr(ctrl2d), ctrl2d.shape[-1], _ptr(comb), _ptr(noise), int(excitation),
                   int(noise_seed), B, Fr, int(hop), _ptr(out))
         return out
+
+    # -- a13 -----------------------------------------------------------------------------------
+    def rss_loss(self, x_pred, x_true, n_ffts, alpha=1.0, eps=1e-7, want_grad=False):
+        """-> (loss (1,) device tensor, d loss/d x_pred (B,T) | None) for the given list of scales."""
+        xp = x_pred.detach().contiguous().float()
+        xt = x_true.detach().contiguous().float()
+        B, T = xp.shape
+        if xt.shape != xp.shape:
+            raise ValueError(f"x_pred {tuple(xp.shape)} and x_true {tuple(xt.shape)} must have the same shape")
+        if T % 4:
+            raise ValueError("signal length must be a multiple of 4")
+        arr = (_int * len(n_ffts))(*[int(n) for n in n_ffts])
+        loss = torch.empty(1, device=xp.device, dtype=torch.float32)
+        grad = torch.empty_like(xp) if want_grad else None
+        self.call("ddsp_rss_loss", _ptr(xp), _ptr(xt), B, T, arr, len(n_ffts), float(alpha), float(eps), _ptr(loss),
+                  _ptr(grad))
+        return loss, grad
 
     # -- a14 -----------------------------------------------------------------------------------
     def sola(self, audio, sola_buffer, block, xfade, search, delay):
