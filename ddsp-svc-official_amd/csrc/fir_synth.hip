@@ -54,7 +54,8 @@ struct EpiDynWindow {  // ddsp/core.py:292-303 incl. its quirk: w>1 is zeroed BE
     int n;
     const float* f0;  // per row
     float sr15;       // 1.5 * sr as fp32
-    __device__ __forceinline__ void operator()(int, int m, int k, float v) const {
+    __device__ __forceinline__ float col(int) const { return 0.f; }
+    __device__ __forceinline__ void operator()(int, int m, int k, float v, float) const {
         const float hw = __fdiv_rn(sr15, __fadd_rn(f0[m], 1e-3f));
         float w = __fdiv_rn((float)(k - n / 2), hw);
         if (w > 1.0f) w = 0.0f;

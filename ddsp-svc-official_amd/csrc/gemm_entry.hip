@@ -1,0 +1,40 @@
+// Plain GEMM entry point of the fp32-MFMA kernel: unit tests of the building block and tile/schedule A/B timing.
+#include "gemm_f32.h"
+
+extern "C" int ddsp_gemm_f32(ddsp_ctx* ctx, void* stream, const float* A, int64_t lda, int a_k_contig, const float* B,
+                             int64_t ldb, int b_k_contig, const float* bias, float* C, int64_t ldc, int M, int N, int K,
+                             int tile, int variant) {
+    DDSP_REQUIRE(ctx, ctx && A && B && C, "ddsp_gemm_f32: null argument");
+    DDSP_REQUIRE(ctx, M >= 1 && N >= 1 && K >= 1 && lda >= 1 && ldb >= 1 && ldc >= N, "ddsp_gemm_f32: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    gemm::Args g = gemm::make(A, lda, B, ldb, M, N, K);
+    gemm::EpiStore e{C, ldc, bias, 1, 0, 0};
+    ddsp_prof_begin(ctx, st, PF_OTHER);
+#define GO(BM, BN, AK, BK_, NW) gemm::launch_tile<BM, BN, AK, BK_, gemm::A_PLAIN, gemm::EpiStore, NW>(st, g, 1, e)
+#define TILE(AK, BK_)                                                        \
+    if (tile == 0) gemm::launch<AK, BK_, gemm::A_PLAIN>(st, g, 1, e);        \
+    else if (tile == 1) GO(64, 64, AK, BK_, 4);                              \
+    else if (tile == 2) GO(64, 128, AK, BK_, 4);                             \
+    else if (tile == 3) GO(128, 128, AK, BK_, 4);                            \
+    else if (tile == 4) GO(128, 128, AK, BK_, 8);                            \
+    else if (tile == 5) GO(128, 64, AK, BK_, 8);                             \
+    else GO(256, 128, AK, BK_, 8);
+    if (tile >= 10) {
+        DDSP_REQUIRE(ctx, a_k_contig && b_k_contig && gemm::dma_ok(g), "ddsp_gemm_f32: DMA tiles need row-major A, [N][K] B, K % 32 == 0, aligned rows");
+        if (tile == 10) gemm::launch_dma<128, 64>(st, g, 1, e);
+        else if (tile == 11) gemm::launch_dma<128, 128>(st, g, 1, e);
+        else gemm::launch_dma<256, 128>(st, g, 1, e);
+    } else if (a_k_contig && b_k_contig) {
+        TILE(true, true)
+    } else if (a_k_contig && !b_k_contig) {
+        TILE(true, false)
+    } else if (!a_k_contig && !b_k_contig) {
+        TILE(false, false)
+    } else {
+        TILE(false, true)
+    }
+    ddsp_prof_end(ctx, st, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}

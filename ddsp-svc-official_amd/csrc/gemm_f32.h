@@ -50,9 +50,12 @@ struct epi_wants_pair : std::false_type {};
 template <class E>
 struct epi_wants_pair<E, std::void_t<decltype(E::kPair)>> : std::true_type {};
 
-template <int BM, int BN, bool A_KC, bool B_KC, int A_MODE, class Epi>
-__global__ void __launch_bounds__(256) kernel(Args g, Epi epi) {
-    constexpr int TM = BM / 64, TN = BN / 64;
+template <int BM, int BN, bool A_KC, bool B_KC, int A_MODE, class Epi, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) kernel(Args g, Epi epi) {
+    // wave grid: 2x2 (NW = 4) or 4(M) x 2(N) (NW = 8); wave tile = TM x TN MFMA tiles of 32x32
+    constexpr int WGM = NW / 2, WGN = 2, NT = 64 * NW;
+    constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
+    static_assert(TM >= 1 && TN >= 1, "tile too small for the wave grid");
     constexpr int LDM = BM + 1, LDN = BN + 1;
     __shared__ float lds[2 * BK * (LDM + LDN)];
     float* const As0 = lds;                 // two [BK][LDM] buffers
@@ -61,8 +64,8 @@ __global__ void __launch_bounds__(256) kernel(Args g, Epi epi) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = (wave >> 1) * (BM / 2);
-    const int wn = (wave & 1) * (BN / 2);
+    const int wm = (wave >> 1) * (BM / WGM);
+    const int wn = (wave & 1) * (BN / WGN);
     const int m0 = blockIdx.y * BM;
     const int n0 = blockIdx.x * BN;
     const int z = blockIdx.z;
@@ -70,40 +73,47 @@ __global__ void __launch_bounds__(256) kernel(Args g, Epi epi) {
     const float* __restrict__ B = g.B + (int64_t)(z / g.zdiv) * g.sB_hi + (int64_t)(z % g.zdiv) * g.sB_lo;
 
     // staging registers: BM*BK/256/4 float4 for A, BN*BK/256/4 for B
-    constexpr int NA = BM * BK / 1024, NB = BN * BK / 1024;
+    constexpr int NA = BM * BK / (4 * NT), NB = BN * BK / (4 * NT);
+    static_assert(NA >= 1 && NB >= 1, "tile too small for the thread count");
     f32x4 ra[NA], rb[NB];
 
+    // Interior tiles (the common case) take a branch-free path; edge tiles bounds-check every element.
     auto load_tiles = [&](int k0) {
+        const bool k_full = (k0 + BK <= g.K);
+        const bool a_full = k_full && (m0 + BM <= g.M);
+        const bool b_full = k_full && (n0 + BN <= g.N);
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int q = tid + i * 256;  // float4 index in the tile
+            const int q = tid + i * NT;  // float4 index in the tile
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (A_KC) {
                 const int r = q / (BK / 4), kq = q % (BK / 4);
                 const int m = m0 + r, k = k0 + kq * 4;
-                if (m < g.M) {
-                    if (A_MODE == A_CONV3) {
-                        // k = tap*Cin + c ; Cin % 4 == 0 so a float4 never straddles taps
-                        if (k < g.K) {
-                            const int tap = k / g.Cin, c = k - tap * g.Cin;
-                            const int f = m % g.Fr + tap - 1;
-                            if (f >= 0 && f < g.Fr) v = *(const f32x4_u*)(A + (int64_t)(m + tap - 1) * g.lda + c);
-                        }
+                if (A_MODE == A_CONV3) {
+                    // k = tap*Cin + c ; Cin % 4 == 0 so a float4 never straddles taps
+                    if (m < g.M && k < g.K) {
+                        const int tap = k / g.Cin, c = k - tap * g.Cin;
+                        const int f = m % g.Fr + tap - 1;
+                        if (f >= 0 && f < g.Fr) v = *(const f32x4_u*)(A + (int64_t)(m + tap - 1) * g.lda + c);
+                    }
+                } else if (a_full) {
+                    v = *(const f32x4_u*)(A + (int64_t)m * g.lda + k);
+                } else if (m < g.M) {
+                    const float* p = A + (int64_t)m * g.lda + k;
+                    if (k + 3 < g.K) {
+                        v = *(const f32x4_u*)p;
                     } else {
-                        const float* p = A + (int64_t)m * g.lda + k;
-                        if (k + 3 < g.K) {
-                            v = *(const f32x4_u*)p;
-                        } else {
-                            if (k < g.K) v[0] = p[0];
-                            if (k + 1 < g.K) v[1] = p[1];
-                            if (k + 2 < g.K) v[2] = p[2];
-                        }
+                        if (k < g.K) v[0] = p[0];
+                        if (k + 1 < g.K) v[1] = p[1];
+                        if (k + 2 < g.K) v[2] = p[2];
                     }
                 }
             } else {
                 const int kr = q / (BM / 4), mq = q % (BM / 4);
                 const int k = k0 + kr, m = m0 + mq * 4;
-                if (k < g.K) {
+                if (a_full) {
+                    v = *(const f32x4_u*)(A + (int64_t)k * g.lda + m);
+                } else if (k < g.K) {
                     const float* p = A + (int64_t)k * g.lda + m;
                     if (m + 3 < g.M) {
                         v = *(const f32x4_u*)p;
@@ -118,12 +128,14 @@ __global__ void __launch_bounds__(256) kernel(Args g, Epi epi) {
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int q = tid + i * 256;
+            const int q = tid + i * NT;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (B_KC) {
                 const int r = q / (BK / 4), kq = q % (BK / 4);
                 const int n = n0 + r, k = k0 + kq * 4;
-                if (n < g.N) {
+                if (b_full) {
+                    v = *(const f32x4_u*)(B + (int64_t)n * g.ldb + k);
+                } else if (n < g.N) {
                     const float* p = B + (int64_t)n * g.ldb + k;
                     if (k + 3 < g.K) {
                         v = *(const f32x4_u*)p;
@@ -136,7 +148,9 @@ __global__ void __launch_bounds__(256) kernel(Args g, Epi epi) {
             } else {
                 const int kr = q / (BN / 4), nq = q % (BN / 4);
                 const int k = k0 + kr, n = n0 + nq * 4;
-                if (k < g.K) {
+                if (b_full) {
+                    v = *(const f32x4_u*)(B + (int64_t)k * g.ldb + n);
+                } else if (k < g.K) {
                     const float* p = B + (int64_t)k * g.ldb + n;
                     if (n + 3 < g.N) {
                         v = *(const f32x4_u*)p;
@@ -156,7 +170,7 @@ __global__ void __launch_bounds__(256) kernel(Args g, Epi epi) {
         float* bs = Bs0 + buf * (BK * LDN);
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int q = tid + i * 256;
+            const int q = tid + i * NT;
             if (A_KC) {
                 const int r = q / (BK / 4), kq = q % (BK / 4);
 #pragma unroll
@@ -169,7 +183,7 @@ __global__ void __launch_bounds__(256) kernel(Args g, Epi epi) {
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int q = tid + i * 256;
+            const int q = tid + i * NT;
             if (B_KC) {
                 const int r = q / (BK / 4), kq = q % (BK / 4);
 #pragma unroll
@@ -198,20 +212,36 @@ __global__ void __launch_bounds__(256) kernel(Args g, Epi epi) {
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tiles((kt + 1) * BK);
-        const float* as = As0 + buf * (BK * LDM) + wm + lr;
-        const float* bs = Bs0 + buf * (BK * LDN) + wn + lr;
+        const float* as = As0 + buf * (BK * LDM) + wm + lr + lh * LDM;
+        const float* bs = Bs0 + buf * (BK * LDN) + wn + lr + lh * LDN;
+        // operand fetch is software-pipelined one k-pair ahead of the MFMAs that consume it
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = as[32 * i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = bs[32 * j];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float a[TM], b[TN];
+            float an[TM], bn[TN];
+            if (kk + 2 < BK) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = as[(kk + lh) * LDM + 32 * i];
+                for (int i = 0; i < TM; ++i) an[i] = as[(kk + 2) * LDM + 32 * i];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = bs[(kk + lh) * LDN + 32 * j];
+                for (int j = 0; j < TN; ++j) bn[j] = bs[(kk + 2) * LDN + 32 * j];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            // pin the order [LDS reads of k-pair kk+2][MFMAs of k-pair kk] (hipcc otherwise sinks the reads
+            // back to just before their use, re-exposing the LDS latency every 4 MFMAs)
+            if (kk + 2 < BK) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = an[i];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = bn[j];
+            }
         }
         if (kt + 1 < nk) store_tiles(buf ^ 1);
         __syncthreads();
@@ -223,38 +253,226 @@ __global__ void __launch_bounds__(256) kernel(Args g, Epi epi) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn + 32 * j + lr;
+            const bool n_ok = n < g.N;
+            // per-column operand of the epilogue (bias), fetched once instead of once per accumulator register
+            const float cb = n_ok ? epi.col(n) : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if constexpr (epi_wants_pair<Epi>::value) {
                     // columns (2f, 2f+1) sit on adjacent lanes: hand each lane its neighbour's value too
                     const float other = __shfl_xor(acc[i][j][r], 1, 64);
-                    if (m < g.M && n < g.N) epi(z, m, n, acc[i][j][r], other);
+                    if (n_ok && m < g.M) epi(z, m, n, acc[i][j][r], other);
                 } else {
-                    if (m < g.M && n < g.N) epi(z, m, n, acc[i][j][r]);
+                    if (n_ok && m < g.M) epi(z, m, n, acc[i][j][r], cb);
                 }
             }
         }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int A_MODE, class Epi>
-inline void launch_tile(hipStream_t st, const Args& g, int batch, const Epi& epi) {
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch);
-    hipLaunchKernelGGL((kernel<BM, BN, A_KC, B_KC, A_MODE, Epi>), grid, dim3(256), 0, st, g, epi);
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS-DMA pipelined variant for the common case (row-major A, nn.Linear-layout B, K % 32 == 0, 16-byte aligned
+// rows): the activations/weights of k-tile t+2 stream HBM/L2 -> LDS with `global_load_lds_dwordx4` (no VGPR
+// staging, no ds_write pass) into a 3-stage ring while tile t feeds the MFMAs; a counted `s_waitcnt vmcnt(N)`
+// keeps one tile in flight across the raw `s_barrier`.  With K = 256..1024 and 8..32 k-tiles per block the
+// register-staged kernel above exposes one global-load latency per k-tile; here it is hidden behind two tiles.
+//
+// LDS image per stage: (BM + BN) rows of 32 floats (128 B), unpadded (one DMA wave-instruction writes 1 KiB =
+// 8 whole rows).  The 16-byte slot p of row r holds global slot p ^ ((r >> 1) & 7) (swizzle applied on the SOURCE
+// address), so that the MFMA operand fetch - lane (i = l&31, h = l>>5) reads its 16 k-values 16h..16h+15 of row i
+// as four ds_read_b128 - is bank-conflict-free.  The MFMA k-order is permuted (step s of lane half h is
+// k = 16h + s) identically for A and B, which leaves the sum unchanged.
+template <int BM, int BN, class Epi>
+__global__ void __launch_bounds__(512) kernel_dma(Args g, Epi epi, int tiles_m, int tiles_n, int total_tiles) {
+    constexpr int NW = 8, WGM = 4, WGN = 2;
+    constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
+    constexpr int ROWS = BM + BN;            // rows per stage
+    constexpr int STAGE = ROWS * 32;         // floats per stage
+    constexpr int PIECES = ROWS / 8;         // 1-KiB DMA pieces per stage
+    constexpr int PPW = PIECES / NW;         // pieces per wave
+    static_assert(PIECES % NW == 0, "stage must split evenly over the waves");
+    __shared__ __attribute__((aligned(1024))) float lds[3 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * (BM / WGM), wn = (wave & 1) * (BN / WGN);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int nk = g.K / 32;
+
+    // Persistent workgroup: walks output tiles blockIdx.x, +gridDim.x, ... and treats their k-tiles as ONE stream
+    // (step = tile_i*nk + kt), so the DMA of the next tile's first k-tiles is already in flight while the current
+    // tile's last MFMAs and its epilogue stores run: no per-tile prologue latency.
+    const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int steps = my_tiles * nk;
+
+    // per-lane source pointers (k = 0) of this wave's DMA pieces for a given tile; rows past the edge re-read
+    // the last row (their products are never stored)
+    auto tile_src = [&](int tile, const float* (&src)[PPW]) {
+        const int per_z = tiles_m * tiles_n;
+        const int z = tile / per_z, rem = tile - z * per_z;
+        const int m0 = (rem / tiles_n) * BM, n0 = (rem % tiles_n) * BN;
+        const float* A = g.A + (int64_t)(z / g.zdiv) * g.sA_hi + (int64_t)(z % g.zdiv) * g.sA_lo;
+        const float* B = g.B + (int64_t)(z / g.zdiv) * g.sB_hi + (int64_t)(z % g.zdiv) * g.sB_lo;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int piece = wave + NW * i;
+            const int row = piece * 8 + (lane >> 3);         // row of the stage image
+            const int slot = (lane & 7) ^ ((row >> 1) & 7);  // logical 16-byte slot this lane fetches
+            if (row < BM) {
+                int m = m0 + row;
+                m = m < g.M ? m : g.M - 1;
+                src[i] = A + (int64_t)m * g.lda + slot * 4;
+            } else {
+                int n = n0 + row - BM;
+                n = n < g.N ? n : g.N - 1;
+                src[i] = B + (int64_t)n * g.ldb + slot * 4;
+            }
+        }
+    };
+    auto issue = [&](const float* const (&src)[PPW], int kt, int stage) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int piece = wave + NW * i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + kt * 32),
+                                             (__attribute__((address_space(3))) void*)(lds + stage * STAGE + piece * 256),
+                                             16, 0, 0);
+        }
+    };
+
+    const float* src_cur[PPW];   // tile that step `issued` belongs to
+    int issued = 0;              // next step whose DMA has not been issued yet
+    int issue_tile = 0, issue_kt = 0;
+    if (steps > 0) tile_src((int)blockIdx.x, src_cur);
+    auto issue_next = [&]() {
+        if (issued >= steps) return;
+        issue(src_cur, issue_kt, issued % 3);
+        ++issued;
+        if (++issue_kt == nk) {
+            issue_kt = 0;
+            ++issue_tile;
+            if (issue_tile < my_tiles) tile_src((int)blockIdx.x + issue_tile * (int)gridDim.x, src_cur);
+        }
+    };
+    issue_next();
+    issue_next();
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int kt = 0, tile_i = 0;
+    for (int step = 0; step < steps; ++step) {
+        // step has landed once at most the next step's pieces of THIS wave are still in flight ...
+        if (step + 1 < steps)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... and every other wave says the same; the barrier also fences the reads of stage (step+2)%3 (step-1)
+        __builtin_amdgcn_s_barrier();
+        issue_next();  // step + 2
+        const float* st = lds + (step % 3) * STAGE;
+        f32x4 av[TM][4], bv[TN][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = wm + 32 * i + lr;
+            const float* rp = st + row * 32;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) av[i][c] = *(const f32x4*)(rp + 4 * ((4 * lh + c) ^ ((row >> 1) & 7)));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row = BM + wn + 32 * j + lr;
+            const float* rp = st + row * 32;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bv[j][c] = *(const f32x4*)(rp + 4 * ((4 * lh + c) ^ ((row >> 1) & 7)));
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s >> 2][s & 3], bv[j][s >> 2][s & 3],
+                                                                     acc[i][j], 0, 0, 0);
+        if (++kt == nk) {
+            // ---- epilogue of this tile (stores drain while the next tile's MFMAs run) ----
+            const int tile = (int)blockIdx.x + tile_i * (int)gridDim.x;
+            const int per_z = tiles_m * tiles_n;
+            const int z = tile / per_z, rem = tile - z * per_z;
+            const int m0 = (rem / tiles_n) * BM, n0 = (rem % tiles_n) * BN;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn + 32 * j + lr;
+                    const bool n_ok = n < g.N;
+                    const float cb = n_ok ? epi.col(n) : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if constexpr (epi_wants_pair<Epi>::value) {
+                            const float other = __shfl_xor(acc[i][j][r], 1, 64);
+                            if (n_ok && m < g.M) epi(z, m, n, acc[i][j][r], other);
+                        } else {
+                            if (n_ok && m < g.M) epi(z, m, n, acc[i][j][r], cb);
+                        }
+                        acc[i][j][r] = 0.f;
+                    }
+                }
+            kt = 0;
+            ++tile_i;
+        }
+    }
 }
 
-// Picks the block tile so that the grid has at least ~2 blocks per CU when the problem allows it.
+inline bool dma_ok(const Args& g) {
+    return g.K % 32 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 && ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0 &&
+           g.sA_hi % 4 == 0 && g.sA_lo % 4 == 0 && g.sB_hi % 4 == 0 && g.sB_lo % 4 == 0;
+}
+
+template <int BM, int BN, class Epi>
+inline void launch_dma(hipStream_t st, const Args& g, int batch, const Epi& epi) {
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int total = tiles_m * tiles_n * batch;
+    // resident workgroups per CU by LDS (3 stages of (BM+BN) x 128 B), 8 waves each
+    constexpr int lds_bytes = 3 * (BM + BN) * 128;
+    constexpr int per_cu = (160 * 1024 / lds_bytes) < 2 ? (160 * 1024 / lds_bytes) : 2;
+    int grid = 256 * per_cu;
+    if (grid > total) grid = total;
+    hipLaunchKernelGGL((kernel_dma<BM, BN, Epi>), dim3(grid), dim3(512), 0, st, g, epi, tiles_m, tiles_n, total);
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, int A_MODE, class Epi, int NW = 4>
+inline void launch_tile(hipStream_t st, const Args& g, int batch, const Epi& epi) {
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch);
+    hipLaunchKernelGGL((kernel<BM, BN, A_KC, B_KC, A_MODE, Epi, NW>), grid, dim3(64 * NW), 0, st, g, epi);
+}
+
+// Tile choice (measured on MI355X, tools/gemm_ab.py, fp32 TFLOP/s at M = 11008):
+//   K%32==0, row-major A, [N][K] B  -> persistent LDS-DMA kernel, 128x64 tiles, 8 waves  (69-83 at K=256, N=512..1536)
+//   otherwise                        -> register-staged kernel: 128x64 / 8 waves when the grid fills the chip,
+//                                       64x64 / 4 waves for small or skinny problems.
+// Larger tiles raise FLOP per staged byte (the L2->LDS operand stream, ~4-6 TB/s chip-wide, is what caps these
+// K=256..768 shapes near 85 TFLOP/s) but leave CUs idle at 11008 = 2*43*128 rows; see DESIGN.md section 9.
 template <bool A_KC, bool B_KC, int A_MODE, class Epi>
 inline void launch(hipStream_t st, const Args& g, int batch, const Epi& epi) {
     auto blocks = [&](int bm, int bn) {
         return (int64_t)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch;
     };
-    if (blocks(128, 128) >= 512)
-        launch_tile<128, 128, A_KC, B_KC, A_MODE, Epi>(st, g, batch, epi);
-    else if (blocks(64, 128) >= 384 || g.M <= 64)
-        launch_tile<64, 128, A_KC, B_KC, A_MODE, Epi>(st, g, batch, epi);
+    if constexpr (A_KC && B_KC && A_MODE == A_PLAIN) {
+        if (dma_ok(g) && blocks(128, 64) >= 256) {
+            launch_dma<128, 64, Epi>(st, g, batch, epi);
+            return;
+        }
+    }
+    if (blocks(128, 64) >= 512)
+        launch_tile<128, 64, A_KC, B_KC, A_MODE, Epi, 8>(st, g, batch, epi);
     else
-        launch_tile<64, 64, A_KC, B_KC, A_MODE, Epi>(st, g, batch, epi);
+        launch_tile<64, 64, A_KC, B_KC, A_MODE, Epi, 4>(st, g, batch, epi);
 }
 
 inline Args make(const float* A, int64_t lda, const float* B, int64_t ldb, int M, int N, int K) {
@@ -280,10 +498,10 @@ struct EpiStore {  // C = acc (+ bias[n])
     const float* bias;
     int zdiv;
     int64_t sC_hi, sC_lo;
-    __device__ __forceinline__ void operator()(int z, int m, int n, float v) const {
+    __device__ __forceinline__ float col(int n) const { return bias ? bias[n] : 0.f; }
+    __device__ __forceinline__ void operator()(int z, int m, int n, float v, float cb) const {
         float* c = C + (int64_t)(z / zdiv) * sC_hi + (int64_t)(z % zdiv) * sC_lo;
-        if (bias) v += bias[n];
-        c[(int64_t)m * ldc + n] = v;
+        c[(int64_t)m * ldc + n] = v + cb;
     }
 };
 
@@ -292,9 +510,10 @@ struct EpiResidual {  // C = res + acc + bias[n]   (res may alias C)
     const float* res;
     int64_t ldc;
     const float* bias;
-    __device__ __forceinline__ void operator()(int, int m, int n, float v) const {
+    __device__ __forceinline__ float col(int n) const { return bias[n]; }
+    __device__ __forceinline__ void operator()(int, int m, int n, float v, float cb) const {
         const int64_t o = (int64_t)m * ldc + n;
-        C[o] = res[o] + (v + bias[n]);
+        C[o] = res[o] + (v + cb);
     }
 };
 

@@ -86,28 +86,27 @@ __global__ void __launch_bounds__(64 * 2 * SEG) ltv_fir_kernel(FirArgs g) {
             dst[i] = (live && k >= 0 && k < g.n) ? src[k] : 0.f;
         }
         float* xd = xs + (size_t)f * XS;
-        for (int i = tid; i < XS; i += blockDim.x) xd[i] = 0.f;
-    }
-    __syncthreads();
-    for (int f = 0; f < g.nfr; ++f) {
-        const int m = m_lo + f;
-        if (m < 0 || m > g.Fr) continue;
-        float* xd = xs + (size_t)f * XS;
         const int64_t tb = (int64_t)HOP * (m - 1);
-        for (int z = tid; z < 2 * HOP; z += blockDim.x) {
-            const int64_t t = tb + z;
-            float x = 0.f;
-            if (t >= 0 && t < T) {
-                if (g.excitation == DDSP_EXC_GENERATE) {
-                    x = noise_u(g.seed, (uint64_t)b * T + t);
-                } else {
-                    x = g.audio[(int64_t)b * T + t];
-                    if (g.excitation == DDSP_EXC_UNIT_NOISE) x = __fadd_rn(__fmul_rn(x, 2.0f), -1.0f);
+        // image row r holds data in columns [PADC + 2*(r>>1), PADC + 2*(r>>1) + 64); everything else is zero pad
+        for (int i = tid; i < XS; i += blockDim.x) {
+            const int r = i / RS, cc = i - r * RS - PADC - 2 * (r >> 1);
+            float v = 0.f;
+            if (live && cc >= 0 && cc < 2 * HOPC) {
+                const int z = cc * 16 + r;
+                const int64_t t = tb + z;
+                if (t >= 0 && t < T) {
+                    float x;
+                    if (g.excitation == DDSP_EXC_GENERATE) {
+                        x = noise_u(g.seed, (uint64_t)b * T + t);
+                    } else {
+                        x = g.audio[(int64_t)b * T + t];
+                        if (g.excitation == DDSP_EXC_UNIT_NOISE) x = __fadd_rn(__fmul_rn(x, 2.0f), -1.0f);
+                    }
+                    const float w = (z < HOP) ? (float)z * (1.0f / HOP) : (float)(2 * HOP - z) * (1.0f / HOP);
+                    v = x * w;
                 }
             }
-            const float w = (z < HOP) ? (float)z * (1.0f / HOP) : (float)(2 * HOP - z) * (1.0f / HOP);
-            const int r = z & 15, col = z >> 4;
-            xd[r * RS + PADC + col + 2 * (r >> 1)] = x * w;
+            xd[i] = v;
         }
     }
     __syncthreads();
@@ -121,14 +120,11 @@ __global__ void __launch_bounds__(64 * 2 * SEG) ltv_fir_kernel(FirArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // lane-constant parts of the operand addresses, per k-step s (r = 4s + lk)
-    int a_off[4], b_off[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int r = 4 * s + lk;
-        a_off[s] = IRPAD + c + li - r;
-        b_off[s] = r * RS + PADC + 2 * (r >> 1) + li;
-    }
+    // lane-constant parts of the operand addresses: k-step s uses row r = 4s + lk, so
+    //   A index = a_base + 16q - 4s,   B index = b_base + s*(4*RS + 4) - q     (immediate offsets in s)
+    const int a_base = IRPAD + c + li - lk;
+    const int b_base = lk * RS + PADC + 2 * (lk >> 1) + li;
+    constexpr int BSTEP = 4 * RS + 4;
 
     for (int f = 0; f < g.nfr; ++f) {
         const int m = m_lo + f;
@@ -138,16 +134,42 @@ __global__ void __launch_bounds__(64 * 2 * SEG) ltv_fir_kernel(FirArgs g) {
         int qb = J0 + 15 - cbase;
         if (qa < g.q_lo) qa = g.q_lo;
         if (qb > g.q_hi) qb = g.q_hi;
-        const float* ap = irs + (size_t)f * g.irs;
-        const float* bp = xs + (size_t)f * XS + (J0 - cbase);
-#pragma unroll 2
-        for (int q = qa; q <= qb; ++q) {
+        if (qa > qb) continue;
+        const float* ap = irs + (size_t)f * g.irs + a_base;
+        const float* bp = xs + (size_t)f * XS + (J0 - cbase) + b_base;
+        // software pipeline with two register sets: operands of shift q+1 are fetched from LDS before the MFMAs
+        // of shift q issue (sched_group_barrier pins [8 LDS reads][4 MFMAs]; hipcc otherwise sinks the reads)
+        float a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            a0[s] = ap[16 * qa - 4 * s];
+            b0[s] = bp[s * BSTEP - qa];
+        }
+        int q = qa;
+        for (; q + 1 <= qb; q += 2) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const float a = ap[16 * q + a_off[s]];
-                const float bv = bp[b_off[s] - q];
-                acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[s], 0, 0, 0);
+                a1[s] = ap[16 * (q + 1) - 4 * s];
+                b1[s] = bp[s * BSTEP - (q + 1)];
             }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b0[s], acc[s], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            const int q2 = (q + 2 <= qb) ? q + 2 : qb;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                a0[s] = ap[16 * q2 - 4 * s];
+                b0[s] = bp[s * BSTEP - q2];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], b1[s], acc[s], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+        if (q == qb) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b0[s], acc[s], 0, 0, 0);
         }
     }
     f32x4 o;

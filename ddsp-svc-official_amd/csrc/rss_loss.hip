@@ -53,6 +53,7 @@ struct EpiMag {  // S[z*F + m][f] = |X| + eps ; optionally keep X (interleaved r
     float* X;  // may be null
     int F, Mb, ldx;
     float eps;
+    __device__ __forceinline__ float col(int) const { return 0.f; }
     __device__ __forceinline__ void operator()(int z, int m, int n, float v, float other) const {
         const int64_t row = (int64_t)z * F + m;
         if (X) X[row * ldx + n] = v;
@@ -138,7 +139,8 @@ struct EpiGradFrames {  // grad[z*T + m*N + n] (+)= acc
     int64_t T;
     int N;
     int accumulate;
-    __device__ __forceinline__ void operator()(int z, int m, int n, float v) const {
+    __device__ __forceinline__ float col(int) const { return 0.f; }
+    __device__ __forceinline__ void operator()(int z, int m, int n, float v, float) const {
         float* p = grad + (int64_t)z * T + (int64_t)m * N + n;
         *p = accumulate ? *p + v : v;
     }

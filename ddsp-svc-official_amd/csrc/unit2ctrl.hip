@@ -229,7 +229,8 @@ struct EpiAttnOut {  // out[(b*Fr+n)*512 + h*64 + e] = dinv[(b*Fr+n)*8+h] * acc 
     float* out;
     const float* dinv;
     int Fr;
-    __device__ __forceinline__ void operator()(int z, int m, int e, float v) const {
+    __device__ __forceinline__ float col(int) const { return 0.f; }
+    __device__ __forceinline__ void operator()(int z, int m, int e, float v, float) const {
         const int b = z / H, h = z % H;
         const int64_t row = (int64_t)b * Fr + m;
         out[row * INNER + h * DH + e] = dinv[row * H + h] * v;

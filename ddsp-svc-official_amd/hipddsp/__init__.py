@@ -62,6 +62,7 @@ SIGNATURES = {
     "ddsp_rss_loss": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _c.POINTER(_int), _int, _f32, _f32, _vp, _vp]),
     "ddsp_sola": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp]),
     "ddsp_volume_gate": (_int, [_vp, _vp, _vp, _vp, _f32, _i64, _i64, _int]),
+    "ddsp_gemm_f32": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _i64, _int, _vp, _vp, _i64, _int, _int, _int, _int, _int]),
     "ddsp_profile_begin": (_int, [_vp, _u64]),
     "ddsp_profile_end": (_int, [_vp, _c.POINTER(ProfEntry), _int, _c.POINTER(_int)]),
     "ddsp_unit2ctrl_fwd": (_int, [_vp, _vp, _c.POINTER(U2CWeights), _vp, _vp, _vp, _vp, _vp, _i64,
@@ -232,6 +233,19 @@ class Context:
                   _ptr(add_in), _ptr(out), _ptr(out_sum))
         return out, out_sum
 
+
+    # -- building block ------------------------------------------------------------------------
+    def gemm(self, A, B, bias=None, a_k_contig=True, b_k_contig=True, tile=0, variant=0):
+        """C = op(A) @ op(B) (+bias): A (M,K) or (K,M) when not a_k_contig; B (N,K) or (K,N) when not b_k_contig."""
+        M, K = (A.shape if a_k_contig else A.shape[::-1])
+        N = B.shape[0] if b_k_contig else B.shape[1]
+        C = torch.empty(M, N, device=A.device, dtype=torch.float32)
+        for t in (A, B):
+            if not t.is_cuda or t.stride(1) != 1 or t.dtype != torch.float32:
+                raise ValueError("gemm operands must be fp32 device matrices with unit inner stride")
+        self.call("ddsp_gemm_f32", A.data_ptr(), A.stride(0), int(a_k_contig), B.data_ptr(), B.stride(0), int(b_k_contig),
+                  _ptr(bias), _ptr(C), N, M, N, K, int(tile), int(variant))
+        return C
 
     # -- a10 -----------------------------------------------------------------------------------
     def sins_bank(self, ctrl2d, col0, n_harmonics, f0_frames, phase, B, Fr, hop, sr):

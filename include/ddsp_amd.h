@@ -161,6 +161,15 @@ int ddsp_sola(ddsp_ctx* ctx, void* stream, const float* audio, int64_t n_audio, 
 int ddsp_volume_gate(ddsp_ctx* ctx, void* stream, float* signal, const float* volume, float threshold, int64_t B,
                      int64_t Fr, int hop);
 
+/* ---- building block: fp32-in / fp32-accumulate MFMA GEMM ---------------------------------------- */
+/* C[m][n] = sum_k A(m,k) B(k,n) (+ bias[n]).  a_k_contig: A(m,k) = A[m*lda+k] else A[k*lda+m];
+ * b_k_contig: B(k,n) = B[n*ldb+k] (nn.Linear weight layout) else B[k*ldb+n].  Rows must start 16-byte aligned
+ * (lda, ldb multiples of 4).  tile: 0 = auto, 1 = 64x64, 2 = 64x128, 3 = 128x128; variant: schedule A/B switch.
+ * Exposed for unit tests of the block every contraction of the path is built on and for tile tuning. */
+int ddsp_gemm_f32(ddsp_ctx* ctx, void* stream, const float* A, int64_t lda, int a_k_contig, const float* B,
+                  int64_t ldb, int b_k_contig, const float* bias, float* C, int64_t ldc, int M, int N, int K, int tile,
+                  int variant);
+
 /* ---- measurement: per-kernel-family HIP-event timing on the launch stream --------------------- */
 /* ddsp_profile_begin arms the families in `family_mask` (bit i = family i, see the name returned); while armed,
  * each kernel launch of such a family is bracketed by hipEventRecord on the caller's stream.  ddsp_profile_end
