@@ -31,7 +31,7 @@ constexpr int PADC = 16;
 constexpr int RS = 112;         // row stride of the transposed input image (floats)
 constexpr int XS = 16 * RS;     // floats per frame image
 constexpr int IRPAD = 32;
-constexpr int SEG = 2;          // segments (hops) per block: 4 wavefronts, one 256-sample tile each
+constexpr int SEG = 4;          // segments (hops) per block: 8 wavefronts, one 256-sample tile each; 2 blocks per CU by LDS
 
 __device__ __forceinline__ float noise_u(uint64_t seed, uint64_t idx) {
     // splitmix64 finaliser of a counter: stateless, so every block that needs sample idx regenerates it
@@ -62,7 +62,9 @@ __global__ void __launch_bounds__(64 * 2 * SEG) ltv_fir_kernel(FirArgs g) {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    // wave-uniform on purpose: loop bounds derived from it must live in SGPRs, otherwise hipcc treats the
+    // MFMA loops as divergent and round-trips the accumulators through VGPRs (s_nop + v_accvgpr_read) per iteration
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
     const int s0 = blockIdx.x * SEG;  // first segment of the block
     const int64_t T = (int64_t)g.Fr * HOP;
@@ -75,38 +77,50 @@ __global__ void __launch_bounds__(64 * 2 * SEG) ltv_fir_kernel(FirArgs g) {
     float* xs = lds + (size_t)g.nfr * g.irs;   // [nfr][XS]
 
     // ---- stage filters and windowed input ----------------------------------------------------
+    // (1) zero the input images (pads must read as zero), 16 B per lane
+    for (int i = tid; i < g.nfr * XS / 4; i += blockDim.x) ((f32x4*)xs)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // (2) filter rows: 32 zeros | n taps | zeros; rows of n floats are 8-byte aligned (n is even)
     for (int f = 0; f < g.nfr; ++f) {
         const int m = m_lo + f;
         const bool live = (m >= 0 && m <= g.Fr);
         const int mi = m < g.Fr ? m : g.Fr - 1;
-        const float* src = g.ir + ((int64_t)b * g.Fr + (live ? mi : 0)) * g.n;
-        float* dst = irs + (size_t)f * g.irs;
-        for (int i = tid; i < g.irs; i += blockDim.x) {
-            const int k = i - IRPAD;
-            dst[i] = (live && k >= 0 && k < g.n) ? src[k] : 0.f;
+        const float2* src = (const float2*)(g.ir + ((int64_t)b * g.Fr + (live ? mi : 0)) * g.n);
+        float2* dst = (float2*)(irs + (size_t)f * g.irs);
+        for (int i = tid; i < g.irs / 2; i += blockDim.x) {
+            const int k2 = i - IRPAD / 2;
+            float2 v = {0.f, 0.f};
+            if (live && k2 >= 0 && k2 < g.n / 2) v = src[k2];
+            dst[i] = v;
         }
+    }
+    __syncthreads();
+    // (3) windowed input: one aligned float4 of x per lane and frame, scattered to image rows r..r+3 of one column
+    for (int f = 0; f < g.nfr; ++f) {
+        const int m = m_lo + f;
+        if (m < 0 || m > g.Fr) continue;
         float* xd = xs + (size_t)f * XS;
         const int64_t tb = (int64_t)HOP * (m - 1);
-        // image row r holds data in columns [PADC + 2*(r>>1), PADC + 2*(r>>1) + 64); everything else is zero pad
-        for (int i = tid; i < XS; i += blockDim.x) {
-            const int r = i / RS, cc = i - r * RS - PADC - 2 * (r >> 1);
-            float v = 0.f;
-            if (live && cc >= 0 && cc < 2 * HOPC) {
-                const int z = cc * 16 + r;
-                const int64_t t = tb + z;
-                if (t >= 0 && t < T) {
-                    float x;
-                    if (g.excitation == DDSP_EXC_GENERATE) {
-                        x = noise_u(g.seed, (uint64_t)b * T + t);
-                    } else {
-                        x = g.audio[(int64_t)b * T + t];
-                        if (g.excitation == DDSP_EXC_UNIT_NOISE) x = __fadd_rn(__fmul_rn(x, 2.0f), -1.0f);
-                    }
-                    const float w = (z < HOP) ? (float)z * (1.0f / HOP) : (float)(2 * HOP - z) * (1.0f / HOP);
-                    v = x * w;
+        for (int z = 4 * tid; z < 2 * HOP; z += 4 * blockDim.x) {
+            const int64_t t = tb + z;
+            if (t < 0 || t >= T) continue;
+            f32x4 x;
+            if (g.excitation == DDSP_EXC_GENERATE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = noise_u(g.seed, (uint64_t)b * T + t + e);
+            } else {
+                x = *(const f32x4*)(g.audio + (int64_t)b * T + t);
+                if (g.excitation == DDSP_EXC_UNIT_NOISE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = __fadd_rn(__fmul_rn(x[e], 2.0f), -1.0f);
                 }
             }
-            xd[i] = v;
+            const int r0 = z & 15, col = z >> 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int zz = z + e, r = r0 + e;
+                const float w = (zz < HOP) ? (float)zz * (1.0f / HOP) : (float)(2 * HOP - zz) * (1.0f / HOP);
+                xd[r * RS + PADC + col + 2 * (r >> 1)] = x[e] * w;
+            }
         }
     }
     __syncthreads();
@@ -196,8 +210,9 @@ extern "C" int ddsp_ltv_fir(ddsp_ctx* ctx, void* stream, const float* audio, int
     DDSP_REQUIRE(ctx, hop == HOP, "ddsp_ltv_fir: only hop == 512 is built");
     DDSP_REQUIRE(ctx, n >= 32 && n <= 2046 && (n % 2) == 0, "ddsp_ltv_fir: n must be even, 32..2046");
     DDSP_REQUIRE(ctx, B >= 0 && Fr >= 1 && B <= 65535, "ddsp_ltv_fir: bad shape");
-    DDSP_REQUIRE(ctx, ((uintptr_t)out % 16) == 0 && ((uintptr_t)add_in % 16) == 0 && ((uintptr_t)out_sum % 16) == 0,
-                 "ddsp_ltv_fir: out/add_in/out_sum must be 16-byte aligned");
+    DDSP_REQUIRE(ctx, ((uintptr_t)out % 16) == 0 && ((uintptr_t)add_in % 16) == 0 && ((uintptr_t)out_sum % 16) == 0 &&
+                          ((uintptr_t)audio % 16) == 0 && ((uintptr_t)ir % 8) == 0,
+                 "ddsp_ltv_fir: audio/out/add_in/out_sum must be 16-byte aligned (ir 8-byte)");
     if (B == 0) return DDSP_OK;
     FirArgs g;
     g.audio = audio;
