@@ -22,7 +22,7 @@ struct ddsp_table {
 enum {
     PF_PHASE_SCAN = 0, PF_FIR_ACT, PF_FIR_DFT_GEMM, PF_LTV_FIR, PF_U2C_PREP, PF_U2C_GEMM_CONV3, PF_U2C_GEMM_LINEAR,
     PF_U2C_GEMM_FEAT, PF_U2C_GEMM_CTX, PF_U2C_GEMM_ATTNOUT, PF_U2C_ROWWISE, PF_SINS_BANK, PF_SPECTRAL_OLA,
-    PF_RSS_LOSS, PF_SOLA, PF_UPSAMPLE, PF_OTHER, PF_COUNT
+    PF_RSS_LOSS, PF_SOLA, PF_UPSAMPLE, PF_OTHER, PF_LTV_FIR_BWD, PF_FIR_SYNTH_BWD, PF_U2C_BWD, PF_OPTIM, PF_COUNT
 };
 
 struct ddsp_prof_rec {

@@ -87,7 +87,7 @@ int ddsp_scratch_get(ddsp_ctx* ctx, size_t bytes, void** out) {
 static const char* kFamilyName[PF_COUNT] = {
     "phase_scan", "fir_act", "fir_dft_gemm", "ltv_fir", "u2c_prep", "u2c_gemm_conv3", "u2c_gemm_linear",
     "u2c_gemm_feat", "u2c_gemm_ctx", "u2c_gemm_attnout", "u2c_rowwise", "sins_bank", "spectral_ola", "rss_loss",
-    "sola", "upsample", "other"};
+    "sola", "upsample", "other", "ltv_fir_bwd", "fir_synth_bwd", "u2c_bwd", "optim"};
 
 void ddsp_prof_begin(ddsp_ctx* ctx, hipStream_t st, int id) {
     ctx->prof_open = 0;

@@ -64,6 +64,83 @@ struct EpiDynWindow {  // ddsp/core.py:292-303 incl. its quirk: w>1 is zeroed BE
     }
 };
 
+
+// ---- backward -----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) dyn_window_scale_kernel(float* __restrict__ d_ir, const float* __restrict__ f0,
+                                                               int n, int64_t rows, float sr15) {
+    const int64_t total = rows * n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / n;
+        const int k = (int)(i % n);
+        const float hw = __fdiv_rn(sr15, __fadd_rn(f0[m], 1e-3f));
+        float w = __fdiv_rn((float)(k - n / 2), hw);
+        if (w > 1.0f) w = 0.0f;
+        d_ir[i] *= __fdiv_rn(__fadd_rn(1.0f, cosf(__fmul_rn(3.14159274101257324f, w))), 2.0f);
+    }
+}
+
+// d_ctrl from d_act (gradient w.r.t. the activated responses), one wavefront per frame row
+__global__ void __launch_bounds__(256) fir_act_bwd_kernel(int mode, const float* __restrict__ ctrl, int64_t ld, int M,
+                                                          const float* __restrict__ d_act, int lda, int64_t rows,
+                                                          float* __restrict__ d_ctrl, int64_t ldo) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* src = ctrl + row * ld;
+    const float* g = d_act + row * lda;
+    float* dst = d_ctrl + row * ldo;
+    if (mode != DDSP_FIR_ALLPASS) {
+        const float scale = (mode == DDSP_FIR_STATIC) ? (1.0f / 128.0f) : 1.0f;
+        for (int f = lane; f < M; f += 64) dst[f] = g[f] * (expf(src[f]) * scale);
+        return;
+    }
+    const float pi_f = 3.14159274101257324f;
+    // forward phases again (same arithmetic as fir_act_kernel), kept in registers: up to 16 chunks of 64 bins
+    float th[16], dphi[16];
+    double carry = 0.0;
+    const int nchunk = (M + 63) / 64;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        th[c] = 0.f;
+        dphi[c] = 0.f;
+        if (c < nchunk) {
+            const int f = c * 64 + lane;
+            const float t = (f < M) ? tanhf(src[f]) : 0.f;
+            th[c] = t;
+            double incl = (double)((f < M) ? __fmul_rn(pi_f, t) : 0.f);
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                double nb = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += nb;
+            }
+            const float phi = (float)(carry + incl);
+            carry += __shfl(incl, 63, 64);
+            if (f < M) {
+                double sn, cs;
+                sincos((double)phi, &sn, &cs);
+                dphi[c] = (float)(-sn * (double)g[f] + cs * (double)g[M + f]);
+            }
+        }
+    }
+    // reverse inclusive cumulative sum of dphi over bins, then through pi*tanh
+    float tail = 0.f;
+#pragma unroll
+    for (int c = 15; c >= 0; --c) {
+        if (c < nchunk) {
+            float incl = dphi[c];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                float nb = __shfl_down(incl, o, 64);
+                if (lane + o < 64) incl += nb;
+            }
+            const float G = incl + tail;
+            tail += __shfl(incl, 0, 64);
+            const int f = c * 64 + lane;
+            if (f < M) dst[f] = G * pi_f * (1.0f - th[c] * th[c]);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int ddsp_fir_from_ctrl(ddsp_ctx* ctx, void* stream, int mode, const float* ctrl, int64_t ctrl_ld,
@@ -106,6 +183,46 @@ extern "C" int ddsp_fir_from_ctrl(ddsp_ctx* ctx, void* stream, int mode, const f
         gemm::launch<true, false, gemm::A_PLAIN>(st, g, 1, epi);
     }
     ddsp_prof_end(ctx, st, 2.0 * rows * (double)n * K, 4.0 * rows * (K + n));
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}
+
+extern "C" int ddsp_fir_from_ctrl_bwd(ddsp_ctx* ctx, void* stream, int mode, const float* ctrl, int64_t ctrl_ld,
+                                      int n_mag, const float* f0_frames, int64_t rows, int sr, float* d_ir,
+                                      float* d_ctrl, int64_t d_ctrl_ld) {
+    DDSP_REQUIRE(ctx, ctx && ctrl && d_ir && d_ctrl, "ddsp_fir_from_ctrl_bwd: null argument");
+    DDSP_REQUIRE(ctx, mode >= 0 && mode <= 2, "ddsp_fir_from_ctrl_bwd: unknown mode");
+    DDSP_REQUIRE(ctx, n_mag >= 3 && n_mag <= 1024 && ctrl_ld >= n_mag && d_ctrl_ld >= n_mag && rows >= 0 && rows < (1 << 30),
+                 "ddsp_fir_from_ctrl_bwd: bad shape");
+    DDSP_REQUIRE(ctx, mode != DDSP_FIR_DYNAMIC || f0_frames, "ddsp_fir_from_ctrl_bwd: DYNAMIC needs f0_frames");
+    if (rows == 0) return DDSP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    const int M = n_mag, n = 2 * (n_mag - 1);
+    const int K = (mode == DDSP_FIR_ALLPASS) ? 2 * M : M;
+    const int lda = ddsp_pad4(K);
+    int rc = ddsp_scratch_reserve_bytes(ctx, (size_t)rows * lda * sizeof(float) + 4096);
+    if (rc) return rc;
+    ddsp_scratch_reset(ctx);
+    float* d_act = nullptr;
+    if ((rc = ddsp_scratch_get(ctx, (size_t)rows * lda * sizeof(float), (void**)&d_act))) return rc;
+    float* tab = nullptr;
+    const int kind = mode == DDSP_FIR_ALLPASS ? TAB_IRDFT_CPLX : (mode == DDSP_FIR_STATIC ? TAB_IRDFT_RE_HANN : TAB_IRDFT_RE);
+    if ((rc = ddsp_get_table(ctx, st, kind, M, 0, &tab))) return rc;
+    ddsp_prof_begin(ctx, st, PF_FIR_SYNTH_BWD);
+    if (mode == DDSP_FIR_DYNAMIC) {
+        int64_t blocks = ceil_div64(rows * n, 256);
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(dyn_window_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_ir, f0_frames, n, rows,
+                           1.5f * (float)sr);
+    }
+    // d_act[m][f] = sum_k d_ir[m][k] * T[f][k]
+    gemm::Args g = gemm::make(d_ir, n, tab, ddsp_pad4(n), (int)rows, K, n);
+    gemm::EpiStore e{d_act, lda, nullptr, 1, 0, 0};
+    gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e);
+    hipLaunchKernelGGL(fir_act_bwd_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, mode, ctrl, ctrl_ld, M,
+                       d_act, lda, rows, d_ctrl, d_ctrl_ld);
+    ddsp_prof_end(ctx, st, 2.0 * rows * (double)n * K, 4.0 * rows * (2.0 * K + n));
     DDSP_LAUNCH_CHECK(ctx);
     return DDSP_OK;
 }

@@ -43,6 +43,49 @@ __device__ __forceinline__ float noise_u(uint64_t seed, uint64_t idx) {
     return u * 2.0f - 1.0f;                                       // exact in fp32
 }
 
+// acc[s] += sum_{q=qa..qb} A_q * B_q for the four k-steps s of a 16x16x16 Toeplitz-block product:
+//   a = ap[16q + SA*4s], b = bp[s*bstep + SB*q]   (lane-constant parts already folded into ap / bp).
+// Software-pipelined with two register sets: operands of shift q+1 are fetched from LDS before the MFMAs of
+// shift q issue (sched_group_barrier pins [8 LDS reads][4 MFMAs]; hipcc otherwise sinks the reads).
+// qa, qb MUST be wave-uniform (SGPR) values - see the readfirstlane note in the kernels.
+template <int SA, int SB>
+__device__ __forceinline__ void toeplitz_accumulate(const float* __restrict__ ap, const float* __restrict__ bp,
+                                                    int bstep, int qa, int qb, f32x4 (&acc)[4]) {
+    if (qa > qb) return;
+    float a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        a0[s] = ap[16 * qa + SA * 4 * s];
+        b0[s] = bp[s * bstep + SB * qa];
+    }
+    int q = qa;
+    for (; q + 1 <= qb; q += 2) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            a1[s] = ap[16 * (q + 1) + SA * 4 * s];
+            b1[s] = bp[s * bstep + SB * (q + 1)];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b0[s], acc[s], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        const int q2 = (q + 2 <= qb) ? q + 2 : qb;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            a0[s] = ap[16 * q2 + SA * 4 * s];
+            b0[s] = bp[s * bstep + SB * q2];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], b1[s], acc[s], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+    if (q == qb) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b0[s], acc[s], 0, 0, 0);
+    }
+}
+
 struct FirArgs {
     const float* audio;  // (B,T) or null
     int excitation;      // DDSP_EXC_*
@@ -148,43 +191,9 @@ __global__ void __launch_bounds__(64 * 2 * SEG) ltv_fir_kernel(FirArgs g) {
         int qb = J0 + 15 - cbase;
         if (qa < g.q_lo) qa = g.q_lo;
         if (qb > g.q_hi) qb = g.q_hi;
-        if (qa > qb) continue;
         const float* ap = irs + (size_t)f * g.irs + a_base;
         const float* bp = xs + (size_t)f * XS + (J0 - cbase) + b_base;
-        // software pipeline with two register sets: operands of shift q+1 are fetched from LDS before the MFMAs
-        // of shift q issue (sched_group_barrier pins [8 LDS reads][4 MFMAs]; hipcc otherwise sinks the reads)
-        float a0[4], b0[4], a1[4], b1[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            a0[s] = ap[16 * qa - 4 * s];
-            b0[s] = bp[s * BSTEP - qa];
-        }
-        int q = qa;
-        for (; q + 1 <= qb; q += 2) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                a1[s] = ap[16 * (q + 1) - 4 * s];
-                b1[s] = bp[s * BSTEP - (q + 1)];
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b0[s], acc[s], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            const int q2 = (q + 2 <= qb) ? q + 2 : qb;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                a0[s] = ap[16 * q2 - 4 * s];
-                b0[s] = bp[s * BSTEP - q2];
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], b1[s], acc[s], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        }
-        if (q == qb) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b0[s], acc[s], 0, 0, 0);
-        }
+        toeplitz_accumulate<-1, -1>(ap, bp, BSTEP, qa, qb, acc);
     }
     f32x4 o;
 #pragma unroll
@@ -195,6 +204,169 @@ __global__ void __launch_bounds__(64 * 2 * SEG) ltv_fir_kernel(FirArgs g) {
     if (g.out_sum) {
         const f32x4 ad = *(const f32x4*)(g.add_in + u);
         *(f32x4*)(g.out_sum + u) = ad + o;
+    }
+}
+
+
+// ---- backward ---------------------------------------------------------------------------------------------
+// y[u] = sum_m sum_k ir_m[k] * (x*W_m)[u + c - k]  (c = n/2).  Two adjoints are needed for training:
+//   (1) d_x[t]     = sum_{m in {s, s+1}} W_m[t] * sum_k ir_m[k] * d_y[t - c + k]        (s = segment of t)
+//   (2) d_ir[m][k] = sum_z (x*W_m)[tb + z] * d_y[tb + z - c + k],  tb = hop*(m-1), z in [0, 2*hop)
+// Both are the same Toeplitz-block products as the forward kernel with other operands.
+
+// (1) input gradient: filters reversed (k' = n-1-k, delay c' = n/2 - 1), d_y staged once UNwindowed, the frame
+// window applied to each frame's accumulator on the way out.  No zero-padding waste: 2 frames x full q range.
+struct FirBwdInArgs {
+    const float* dy;  // (B,T)
+    const float* ir;  // (B,Fr,n)
+    float* dx;        // (B,T)
+    int Fr, n, q_lo, q_hi, irs, rsb, col_off;  // col_off = q_hi (image column 0 = absolute column 32*s0 - q_hi)
+};
+
+__global__ void __launch_bounds__(64 * 2 * SEG) ltv_fir_bwd_input_kernel(FirBwdInArgs g) {
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, s0 = blockIdx.x * SEG;
+    const int64_t T = (int64_t)g.Fr * HOP;
+    const int cp = g.n / 2 - 1;
+    float* irs = lds;                               // [SEG+1][g.irs]  reversed filters of frames s0 .. s0+SEG
+    float* img = lds + (size_t)(SEG + 1) * g.irs;   // [16][g.rsb]     raw d_y, transposed + skewed like the forward image
+    for (int f = 0; f <= SEG; ++f) {
+        const int m = s0 + f;
+        const bool live = m <= g.Fr;
+        const int mi = m < g.Fr ? m : g.Fr - 1;
+        const float* src = g.ir + ((int64_t)b * g.Fr + (live ? mi : 0)) * g.n;
+        float* dst = irs + (size_t)f * g.irs;
+        for (int i = tid; i < g.irs; i += blockDim.x) {
+            const int k = i - IRPAD;
+            dst[i] = (live && k >= 0 && k < g.n) ? src[g.n - 1 - k] : 0.f;
+        }
+    }
+    const int ncol = g.rsb - 16;                    // columns the image must cover (multiple of 16 by construction)
+    const int64_t t_base = 16 * ((int64_t)HOPC * s0 - g.col_off);
+    for (int z = 4 * tid; z < 16 * ncol; z += 4 * blockDim.x) {
+        const int64_t t = t_base + z;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t >= 0 && t < T) v = *(const f32x4*)(g.dy + (int64_t)b * T + t);
+        const int r0 = z & 15, col = z >> 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) img[(r0 + e) * g.rsb + col + 2 * ((r0 + e) >> 1)] = v[e];
+    }
+    __syncthreads();
+    const int seg = s0 + (wave >> 1);
+    if (seg >= g.Fr) return;
+    const int J0 = HOPC * seg + 16 * (wave & 1);
+    const int li = lane & 15, lk = lane >> 4;
+    const int a_base = IRPAD + cp + li - lk;
+    const int b_base = lk * g.rsb + 2 * (lk >> 1) + li + (J0 - (HOPC * s0 - g.col_off));
+    const int bstep = 4 * g.rsb + 4;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    const int j0 = (16 * (J0 - HOPC * seg) + 16 * li + 4 * lk);  // position of this lane's first sample in its segment
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int f = (seg - s0) + which;
+        toeplitz_accumulate<-1, -1>(irs + (size_t)f * g.irs + a_base, img + b_base, bstep, g.q_lo, g.q_hi, acc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float j = (float)(j0 + e) * (1.0f / HOP);
+            const float w = which ? j : 1.0f - j;
+            o[e] = fmaf(w, (acc[0][e] + acc[1][e]) + (acc[2][e] + acc[3][e]), o[e]);
+        }
+    }
+    *(f32x4*)(g.dx + (int64_t)b * T + 16 * (int64_t)(J0 + li) + 4 * lk) = o;
+}
+
+// (2) filter gradient: one workgroup per (utterance, frame); "taps" = the windowed input frame (2*hop values),
+// "signal" = d_y around the frame, outputs = the n filter taps.  O[i][j] = d_ir[16(J+j)+i]:
+//   A_q[i][r] = xw[16q + r - i],  B_q[r][j] = d_y[tb - c + 16(J+j+q) + r],  q = 0..2*hop/16.
+struct FirBwdIrArgs {
+    const float* audio;  // forward input (B,T) or null
+    int excitation;
+    uint64_t seed;
+    const float* dy;     // (B,T)
+    float* dir;          // (B,Fr,n)
+    int Fr, n, rsf, tiles;
+};
+
+__global__ void __launch_bounds__(256) ltv_fir_bwd_filter_kernel(FirBwdIrArgs g) {
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, m0 = blockIdx.x;       // frame m0 < Fr; frame Fr (same filter) is folded into Fr-1
+    const int64_t T = (int64_t)g.Fr * HOP;
+    const int c = g.n / 2;
+    constexpr int HROW = 2 * HOP + 2 * IRPAD;        // windowed frame with 32 zeros either side
+    float* hrow = lds;
+    float* img = lds + HROW;                         // [16][g.rsf]
+    const int li = lane & 15, lk = lane >> 4;
+    const int bstep = 4 * g.rsf + 4;
+    const int n_pass = (m0 == g.Fr - 1) ? 2 : 1;
+    f32x4 out[4];                                    // this wave's tiles: wave, wave+4, ... (up to 4 for n <= 4096)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int pass = 0; pass < n_pass; ++pass) {
+        const int m = m0 + pass;
+        const int64_t tb = (int64_t)HOP * (m - 1);
+        __syncthreads();
+        for (int i = tid; i < HROW; i += 256) {
+            const int z = i - IRPAD;
+            float v = 0.f;
+            const int64_t t = tb + z;
+            if (z >= 0 && z < 2 * HOP && t >= 0 && t < T) {
+                float x;
+                if (g.excitation == DDSP_EXC_GENERATE) {
+                    x = noise_u(g.seed, (uint64_t)b * T + t);
+                } else {
+                    x = g.audio[(int64_t)b * T + t];
+                    if (g.excitation == DDSP_EXC_UNIT_NOISE) x = __fadd_rn(__fmul_rn(x, 2.0f), -1.0f);
+                }
+                const float w = (z < HOP) ? (float)z * (1.0f / HOP) : (float)(2 * HOP - z) * (1.0f / HOP);
+                v = x * w;
+            }
+            hrow[i] = v;
+        }
+        const int ncol = g.rsf - 16;
+        for (int z = 4 * tid; z < 16 * ncol; z += 4 * 256) {
+            const int64_t t = tb - c + z;                 // tb and c: t is a multiple of 4 only when c is;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};               // c = n/2 may be odd -> element-wise bounds and loads
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (t + e >= 0 && t + e < T) v[e] = g.dy[(int64_t)b * T + t + e];
+            const int r0 = z & 15, col = z >> 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) img[(r0 + e) * g.rsf + col + 2 * ((r0 + e) >> 1)] = v[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int tile = wave + 4 * it;
+            if (tile < g.tiles) {
+                const int J = 16 * tile;
+                f32x4 acc[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const float* ap = hrow + IRPAD + lk - li;
+                const float* bp = img + lk * g.rsf + 2 * (lk >> 1) + li + J;
+                toeplitz_accumulate<1, 1>(ap, bp, bstep, 0, 2 * HOP / 16, acc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[it][e] += (acc[0][e] + acc[1][e]) + (acc[2][e] + acc[3][e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int tile = wave + 4 * it;
+        if (tile < g.tiles) {
+            const int k0 = 16 * (16 * tile + li) + 4 * lk;
+            float* dst = g.dir + ((int64_t)b * g.Fr + m0) * g.n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k0 + e < g.n) dst[k0 + e] = out[it][e];
+        }
     }
 }
 
@@ -250,6 +422,71 @@ extern "C" int ddsp_ltv_fir(ddsp_ctx* ctx, void* stream, const float* audio, int
         const double flops = nb * T * n * 2.0 * 2.0;
         const double bytes = 4.0 * nb * (T * ((audio ? 1 : 0) + (out ? 1 : 0) + (out_sum ? 2 : 0)) + (double)Fr * n);
         ddsp_prof_end(ctx, (hipStream_t)stream, flops, bytes);
+    }
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}
+
+extern "C" int ddsp_ltv_fir_bwd(ddsp_ctx* ctx, void* stream, const float* audio, int excitation, uint64_t noise_seed,
+                                const float* ir, const float* d_out, int64_t B, int64_t Fr, int hop, int n,
+                                float* d_audio, float* d_ir) {
+    DDSP_REQUIRE(ctx, ctx && ir && d_out && (d_audio || d_ir), "ddsp_ltv_fir_bwd: null argument");
+    DDSP_REQUIRE(ctx, excitation >= 0 && excitation <= 2, "ddsp_ltv_fir_bwd: unknown excitation");
+    DDSP_REQUIRE(ctx, !d_ir || excitation == DDSP_EXC_GENERATE || audio, "ddsp_ltv_fir_bwd: d_ir needs the forward input");
+    DDSP_REQUIRE(ctx, hop == HOP, "ddsp_ltv_fir_bwd: only hop == 512 is built");
+    DDSP_REQUIRE(ctx, n >= 32 && n <= 2046 && (n % 2) == 0, "ddsp_ltv_fir_bwd: n must be even, 32..2046");
+    DDSP_REQUIRE(ctx, B >= 0 && Fr >= 1 && B <= 65535, "ddsp_ltv_fir_bwd: bad shape");
+    DDSP_REQUIRE(ctx, ((uintptr_t)d_out % 16) == 0 && ((uintptr_t)d_audio % 16) == 0, "ddsp_ltv_fir_bwd: d_out/d_audio must be 16-byte aligned");
+    if (B == 0) return DDSP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    static bool attr_set = false;
+    if (!attr_set) {
+        DDSP_HIP(ctx, hipFuncSetAttribute((const void*)ltv_fir_bwd_input_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DDSP_HIP(ctx, hipFuncSetAttribute((const void*)ltv_fir_bwd_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const double Ts = (double)Fr * HOP;
+    if (d_audio) {
+        FirBwdInArgs g;
+        g.dy = d_out;
+        g.ir = ir;
+        g.dx = d_audio;
+        g.Fr = (int)Fr;
+        g.n = n;
+        const int cp = n / 2 - 1;
+        g.q_lo = -((cp + 15) / 16);
+        g.q_hi = (cp + 14) / 16;
+        g.irs = (n + 2 * IRPAD + 3) & ~3;
+        g.col_off = g.q_hi;
+        // image columns: [32*s0 - q_hi, 32*(s0+SEG) - 1 - q_lo] (+ up to 14 of skew), row stride = 16 (mod 32)
+        const int width = HOPC * SEG + g.q_hi - g.q_lo;
+        const int ncol = (width + 31) & ~31;   // multiple of 32 -> row stride = 16 (mod 32): conflict-free operand fetch
+        g.rsb = ncol + 16;
+        const size_t lds_bytes = ((size_t)(SEG + 1) * g.irs + 16 * (size_t)g.rsb) * sizeof(float);
+        DDSP_REQUIRE(ctx, lds_bytes <= 160 * 1024, "ddsp_ltv_fir_bwd: filter too long for the LDS staging");
+        ddsp_prof_begin(ctx, st, PF_LTV_FIR_BWD);
+        hipLaunchKernelGGL(ltv_fir_bwd_input_kernel, dim3((unsigned)((Fr + SEG - 1) / SEG), (unsigned)B),
+                           dim3(64 * 2 * SEG), lds_bytes, st, g);
+        ddsp_prof_end(ctx, st, (double)B * Ts * n * 4.0, 4.0 * B * (2.0 * Ts + (double)Fr * n));
+    }
+    if (d_ir) {
+        FirBwdIrArgs g;
+        g.audio = audio;
+        g.excitation = excitation;
+        g.seed = noise_seed;
+        g.dy = d_out;
+        g.dir = d_ir;
+        g.Fr = (int)Fr;
+        g.n = n;
+        g.tiles = (n + 255) / 256;
+        // signal positions used: [0, 2*hop - 1 + n) -> columns, + skew, row stride = 16 (mod 32)
+        const int ncol = ((2 * HOP + n + 15) / 16 + 16 + 31) & ~31;
+        g.rsf = ncol + 16;
+        const size_t lds_bytes = ((size_t)(2 * HOP + 2 * IRPAD) + 16 * (size_t)g.rsf) * sizeof(float);
+        ddsp_prof_begin(ctx, st, PF_LTV_FIR_BWD);
+        hipLaunchKernelGGL(ltv_fir_bwd_filter_kernel, dim3((unsigned)Fr, (unsigned)B), dim3(256), lds_bytes, st, g);
+        ddsp_prof_end(ctx, st, (double)B * Ts * n * 4.0, 4.0 * B * (2.0 * Ts + (double)Fr * n));
     }
     DDSP_LAUNCH_CHECK(ctx);
     return DDSP_OK;

@@ -45,7 +45,7 @@ class ProfEntry(_c.Structure):
 
 FAMILIES = ["phase_scan", "fir_act", "fir_dft_gemm", "ltv_fir", "u2c_prep", "u2c_gemm_conv3", "u2c_gemm_linear",
             "u2c_gemm_feat", "u2c_gemm_ctx", "u2c_gemm_attnout", "u2c_rowwise", "sins_bank", "spectral_ola", "rss_loss",
-            "sola", "upsample", "other"]
+            "sola", "upsample", "other", "ltv_fir_bwd", "fir_synth_bwd", "u2c_bwd", "optim"]
 
 # name -> (restype, argtypes); every symbol declared in include/ddsp_amd.h must be listed here
 SIGNATURES = {
@@ -57,6 +57,8 @@ SIGNATURES = {
     "ddsp_upsample": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _int, _vp]),
     "ddsp_phase_scan": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "ddsp_fir_from_ctrl": (_int, [_vp, _vp, _int, _vp, _i64, _int, _vp, _i64, _int, _vp]),
+    "ddsp_ltv_fir_bwd": (_int, [_vp, _vp, _vp, _int, _u64, _vp, _vp, _i64, _i64, _int, _int, _vp, _vp]),
+    "ddsp_fir_from_ctrl_bwd": (_int, [_vp, _vp, _int, _vp, _i64, _int, _vp, _i64, _int, _vp, _vp, _i64]),
     "ddsp_sins_bank": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp, _i64, _i64, _int, _int, _vp]),
     "ddsp_spectral_ola": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _int, _u64, _i64, _i64, _int, _vp]),
     "ddsp_rss_loss": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _c.POINTER(_int), _int, _f32, _f32, _vp, _vp]),
@@ -233,6 +235,23 @@ class Context:
                   _ptr(add_in), _ptr(out), _ptr(out_sum))
         return out, out_sum
 
+
+    # -- backward of a5-a8 ---------------------------------------------------------------------
+    def ltv_fir_bwd(self, audio, ir, d_out, B, Fr, hop, excitation=EXC_AUDIO, noise_seed=0, want_d_audio=True,
+                    want_d_ir=True):
+        n = ir.shape[-1]
+        d_out = d_out.contiguous().float()
+        d_audio = torch.empty(B, Fr * hop, device=ir.device, dtype=torch.float32) if want_d_audio else None
+        d_ir = torch.empty(B * Fr, n, device=ir.device, dtype=torch.float32) if want_d_ir else None
+        self.call("ddsp_ltv_fir_bwd", _ptr(audio), int(excitation), int(noise_seed), _ptr(ir), _ptr(d_out), B, Fr,
+                  int(hop), int(n), _ptr(d_audio), _ptr(d_ir))
+        return d_audio, d_ir
+
+    def fir_from_ctrl_bwd(self, mode, ctrl2d, col0, n_mag, rows, sr, d_ir, d_ctrl2d, f0_frames=None):
+        """Writes d ctrl into columns [col0, col0+n_mag) of d_ctrl2d (rows, ld); d_ir is consumed (scaled in place)."""
+        f0 = None if f0_frames is None else f0_frames.reshape(-1).contiguous().float()
+        self.call("ddsp_fir_from_ctrl_bwd", int(mode), _ptr(ctrl2d) + 4 * col0, ctrl2d.shape[-1], int(n_mag), _ptr(f0),
+                  rows, int(sr), _ptr(d_ir), _ptr(d_ctrl2d) + 4 * col0, d_ctrl2d.shape[-1])
 
     # -- building block ------------------------------------------------------------------------
     def gemm(self, A, B, bias=None, a_k_contig=True, b_k_contig=True, tile=0, variant=0):

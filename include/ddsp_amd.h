@@ -120,6 +120,19 @@ int ddsp_unit2ctrl_fwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_weights* weig
                        const int64_t* spk_id, int64_t n_spk_id, const int64_t* mix_ids_host,
                        const float* mix_w_host, int n_mix, int64_t B, int64_t Fr, float* ctrl);
 
+/* ---- backward of a5-a8 (training: reference autograd through frequency_filter, solver.py:113) ------------ */
+/* Adjoints of ddsp_ltv_fir for an upstream gradient d_out (B,T): d_audio (B,T) or NULL = gradient w.r.t. the
+ * input signal; d_ir (B,Fr,n) or NULL = gradient w.r.t. the filter frames (needs the forward input: audio with
+ * its excitation mode, or DDSP_EXC_GENERATE + the same noise_seed). */
+int ddsp_ltv_fir_bwd(ddsp_ctx* ctx, void* stream, const float* audio, int excitation, uint64_t noise_seed,
+                     const float* ir, const float* d_out, int64_t B, int64_t Fr, int hop, int n, float* d_audio,
+                     float* d_ir);
+/* Adjoint of ddsp_fir_from_ctrl: d_ir (rows, n) [scaled in place by the dynamic window in DYNAMIC mode] ->
+ * d_ctrl, written to `n_mag` columns at row stride d_ctrl_ld (a column block of the control-gradient matrix). */
+int ddsp_fir_from_ctrl_bwd(ddsp_ctx* ctx, void* stream, int mode, const float* ctrl, int64_t ctrl_ld, int n_mag,
+                           const float* f0_frames, int64_t rows, int sr, float* d_ir, float* d_ctrl,
+                           int64_t d_ctrl_ld);
+
 /* ---- a10: additive sinusoid bank ----------------------------------------------------------- */
 /* replaces ddsp/vocoder.py:397,402-412 + ddsp/core.py:24-28: amplitudes exp(ctrl)/128 masked by
  * ((k*f0 < sr/2) + 1e-7), upsampled per harmonic, times sin(k*phase), summed over k = 1..n_harmonics.
