@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(256) attn_denominator_kernel(const float* __re
     if (lane == 0) dinv[r] = 1.0f / (s + 1e-8f);
 }
 
-struct EpiAttnOut {  // out[(b*Fr+n)*512 + h*64 + e] = dinv[(b*Fr+n)*8+h] * acc   (z = b*8+h, m = n, col = e)
+struct EpiAttnOut {  // out[(b*Fr+n)*512 + h*64 + e] = dinv[(b*Fr+n)*8+h] * acc   (z = b*8+h, m = n, col = e); dinv null -> 1
     float* out;
     const float* dinv;
     int Fr;
@@ -233,7 +233,7 @@ struct EpiAttnOut {  // out[(b*Fr+n)*512 + h*64 + e] = dinv[(b*Fr+n)*8+h] * acc 
     __device__ __forceinline__ void operator()(int z, int m, int e, float v, float) const {
         const int b = z / H, h = z % H;
         const int64_t row = (int64_t)b * Fr + m;
-        out[row * INNER + h * DH + e] = dinv[row * H + h] * v;
+        out[row * INNER + h * DH + e] = dinv ? dinv[row * H + h] * v : v;
     }
 };
 
@@ -257,15 +257,18 @@ __global__ void __launch_bounds__(256) glu_kernel(const float* __restrict__ g1, 
 // sliding window of DW_RUN+30 inputs stay in registers (2.9 loads per output instead of 31); lanes walk
 // channels, so every load/store of a wavefront is one contiguous 256-B row segment.
 constexpr int DW_RUN = 16;
-__global__ void __launch_bounds__(256) dwconv_silu_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          const float* __restrict__ bias, int B, int Fr,
-                                                          float* __restrict__ out) {
+// SILU: apply SiLU (forward) and optionally keep the pre-activation; FLIP: correlate with reversed taps and no
+// bias (the input-gradient of the same convolution).
+template <bool SILU, bool FLIP>
+__global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, int B, int Fr,
+                                                     float* __restrict__ out, float* __restrict__ pre) {
     const int c = blockIdx.x * 256 + threadIdx.x;       // channel (INNER = 512 -> 2 blocks in x)
     const int runs = (Fr + DW_RUN - 1) / DW_RUN;
     const int b = blockIdx.y / runs, f0 = (blockIdx.y % runs) * DW_RUN;
     float wt[DWK];
 #pragma unroll
-    for (int t = 0; t < DWK; ++t) wt[t] = w[c * DWK + t];
+    for (int t = 0; t < DWK; ++t) wt[t] = w[c * DWK + (FLIP ? DWK - 1 - t : t)];
     const float* xb = x + ((int64_t)b * Fr) * INNER + c;
     float win[DW_RUN + DWK - 1];
 #pragma unroll
@@ -273,13 +276,407 @@ __global__ void __launch_bounds__(256) dwconv_silu_kernel(const float* __restric
         const int f = f0 + i - DWK / 2;
         win[i] = (f >= 0 && f < Fr) ? xb[(int64_t)f * INNER] : 0.f;
     }
-    const float bi = bias[c];
+    const float bi = FLIP ? 0.f : bias[c];
 #pragma unroll
     for (int o = 0; o < DW_RUN; ++o) {
         float acc = bi;
 #pragma unroll
         for (int t = 0; t < DWK; ++t) acc = fmaf(wt[t], win[o + t], acc);
-        if (f0 + o < Fr) out[((int64_t)b * Fr + f0 + o) * INNER + c] = acc * (1.0f / (1.0f + expf(-acc)));
+        if (f0 + o < Fr) {
+            const int64_t idx = ((int64_t)b * Fr + f0 + o) * INNER + c;
+            if (SILU) {
+                if (pre) pre[idx] = acc;
+                out[idx] = acc * (1.0f / (1.0f + expf(-acc)));
+            } else {
+                out[idx] = acc;
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// Backward kernels (training).  Every contraction is again a GEMM on the fp32 matrix pipe (dX = dY W,
+// dW = dY^T X as split-K batches + a reduction); the kernels below are the row-wise adjoints around them.
+// =====================================================================================================
+
+// LayerNorm backward, one wave per row: dx = rstd*(dy*g - mean(dy*g) - xhat*mean(dy*g*xhat)) (+ res);
+// gx = dy*xhat is written for the column reduction that yields d gamma.
+__global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ dy, const float* __restrict__ res,
+                                                            int64_t rows, float* __restrict__ dx,
+                                                            float* __restrict__ gx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= rows) return;
+    const f32x4 v = *(const f32x4*)(x + m * D + lane * 4);
+    const f32x4 g = *(const f32x4*)(dy + m * D + lane * 4);
+    const f32x4 ga = *(const f32x4*)(gamma + lane * 4);
+    const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / D);
+    f32x4 xh, dg;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        xh[j] = v[j] - mean;
+        ss = fmaf(xh[j], xh[j], ss);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) * (1.0f / D) + 1e-5f);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        xh[j] *= rstd;
+        dg[j] = g[j] * ga[j];
+        s1 += dg[j];
+        s2 = fmaf(dg[j], xh[j], s2);
+    }
+    s1 = wave_sum(s1) * (1.0f / D);
+    s2 = wave_sum(s2) * (1.0f / D);
+    f32x4 o, gxo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        o[j] = rstd * (dg[j] - s1 - xh[j] * s2);
+        gxo[j] = g[j] * xh[j];
+    }
+    if (res) o += *(const f32x4*)(res + m * D + lane * 4);
+    *(f32x4*)(dx + m * D + lane * 4) = o;
+    *(f32x4*)(gx + m * D + lane * 4) = gxo;
+}
+
+// Column sums over rows, optionally weighted per row: out_partial[chunk][c] = sum_{r in chunk} X[r][c] * w(r).
+// wmode: 0 none, 1 w = wsrc[r], 2 w = ln(1 + wsrc[r]/700), 3 w = wsrc[r]/pi     (the three side embeddings)
+constexpr int CS_CHUNKS = 64;
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ X, int64_t ld, int64_t rows,
+                                                             int cols, const float* __restrict__ wsrc, int wmode,
+                                                             float* __restrict__ partial) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int64_t per = (rows + CS_CHUNKS - 1) / CS_CHUNKS;
+    const int64_t r0 = (int64_t)blockIdx.y * per;
+    int64_t r1 = r0 + per;
+    if (r1 > rows) r1 = rows;
+    float s = 0.f;
+    if (c < cols) {
+        for (int64_t r = r0 + rl; r < r1; r += 4) {
+            float w = 1.0f;
+            if (wmode == 1) w = wsrc[r];
+            else if (wmode == 2) w = logf(1.0f + __fdiv_rn(wsrc[r], 700.0f));
+            else if (wmode == 3) w = __fdiv_rn(wsrc[r], 3.14159274101257324f);
+            s = fmaf(X[r * ld + c], w, s);
+        }
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && c < cols)
+        partial[(int64_t)blockIdx.y * cols + c] = (red[threadIdx.x] + red[threadIdx.x + 64]) +
+                                                  (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+}
+
+// out[i] = sum_{z < nz} partial[z][i]  (also the split-K reduction of the weight-gradient GEMMs)
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __restrict__ partial, int nz, int64_t n,
+                                                              float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < nz; ++z) s += partial[(int64_t)z * n + i];
+        out[i] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256) silu_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ dout,
+                                                       int64_t n, float* __restrict__ dpre) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float p = pre[i], sg = 1.0f / (1.0f + expf(-p));
+        dpre[i] = dout[i] * (sg * (1.0f + p * (1.0f - sg)));
+    }
+}
+
+// GLU backward: g1 = [a | g] (rows x 1024), out = a*sigmoid(g): d_a = d*s, d_g = d*a*s*(1-s)
+__global__ void __launch_bounds__(256) glu_bwd_kernel(const float* __restrict__ g1, const float* __restrict__ dglu,
+                                                      int64_t rows, float* __restrict__ dg1) {
+    const int64_t total = rows * INNER;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / INNER;
+        const int c = (int)(i % INNER);
+        const float a = g1[m * 2 * INNER + c], g = g1[m * 2 * INNER + INNER + c], d = dglu[i];
+        const float sg = 1.0f / (1.0f + expf(-g));
+        dg1[m * 2 * INNER + c] = d * sg;
+        dg1[m * 2 * INNER + INNER + c] = d * a * sg * (1.0f - sg);
+    }
+}
+
+// depthwise-conv weight gradient: partial[b][c][t] = sum_f dpre[b,f,c] * x[b, f+t-15, c]; block = (64 channels, utterance)
+__global__ void __launch_bounds__(256) dwconv_wgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ x,
+                                                           int Fr, float* __restrict__ partial) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int tg = threadIdx.x >> 6;  // taps tg, tg+4, ...
+    const int b = blockIdx.y;
+    const float* dp = dpre + ((int64_t)b * Fr) * INNER + c;
+    const float* xp = x + ((int64_t)b * Fr) * INNER + c;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int f = 0; f < Fr; ++f) {
+        const float d = dp[(int64_t)f * INNER];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int t = tg + 4 * i;
+            const int ff = f + t - DWK / 2;
+            if (t < DWK && ff >= 0 && ff < Fr) acc[i] = fmaf(d, xp[(int64_t)ff * INNER], acc[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int t = tg + 4 * i;
+        if (t < DWK) partial[((int64_t)b * INNER + c) * DWK + t] = acc[i];
+    }
+}
+
+// attention output adjoint, one wave per (frame, head) row: out = num * dinv  ->  d_num = d_out*dinv (in place),
+// d_D = -(d_out . out) * dinv
+__global__ void __launch_bounds__(256) attn_out_bwd_kernel(float* __restrict__ d_attn, const float* __restrict__ attn,
+                                                           const float* __restrict__ dinv, int64_t rows8,
+                                                           float* __restrict__ dD) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows8) return;
+    const int64_t off = (r / H) * INNER + (r % H) * DH + lane;
+    const float d = d_attn[off], o = attn[off], di = dinv[r];
+    const float dot = wave_sum(d * o);
+    d_attn[off] = d * di;
+    if (lane == 0) dD[r] = -dot * di;
+}
+
+// d_ks[b,h,j] = sum_n q'[b,n,h,j] * d_D[b,n,h]
+__global__ void __launch_bounds__(320) weighted_key_sum_kernel(const float* __restrict__ qf, const float* __restrict__ dD,
+                                                               int Fr, float* __restrict__ dks) {
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int j = threadIdx.x;
+    if (j >= LDF) return;
+    const int64_t r0 = ((int64_t)b * Fr) * H + h;
+    float s = 0.f;
+    for (int n = 0; n < Fr; ++n) s = fmaf(qf[(r0 + (int64_t)n * H) * LDF + j], dD[r0 + (int64_t)n * H], s);
+    dks[(int64_t)bh * LDF + j] = s;
+}
+
+// feature-map adjoint, in place on d_feat: d_feat <- dn * d(dd);  coef[r] = -dn^2 * sum_j d_feat_j * E_j
+// key:   feat_j = r*exp(dd_j - diag + eps)            E_j = feat_j
+// query: feat_j = r*(exp(dd_j - diag - max) + eps)    E_j = feat_j - r*eps, and the max-subtraction routes -sum to argmax
+template <bool QUERY>
+__global__ void __launch_bounds__(256) feature_map_bwd_kernel(const float* __restrict__ feat, float* __restrict__ dfeat,
+                                                              int64_t rows8, float* __restrict__ coef) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows8) return;
+    const float dn = 0.35355339059327373f, ratio = 0.06131393394849658f;
+    const float* f = feat + r * LDF;
+    float* d = dfeat + r * LDF;
+    float dd[5], fv[5];
+    float t = 0.f, best = -3.0e38f;
+    int arg = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int j = lane + 64 * i;
+        dd[i] = 0.f;
+        fv[i] = 0.f;
+        if (j < NF) {
+            fv[i] = f[j];
+            const float E = QUERY ? fv[i] - ratio * 1e-4f : fv[i];
+            dd[i] = d[j] * E;
+            t += dd[i];
+            if (QUERY && (fv[i] > best)) {
+                best = fv[i];
+                arg = j;
+            }
+        }
+    }
+    t = wave_sum(t);
+    if (QUERY) {
+        // first index of the row maximum (torch.max returns one arg max; ties are measure-zero for real data)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oa = __shfl_xor(arg, o, 64);
+            if (ob > best || (ob == best && oa < arg)) {
+                best = ob;
+                arg = oa;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int j = lane + 64 * i;
+        if (j < NF) {
+            float v = dd[i];
+            if (QUERY && j == arg) v -= t;
+            d[j] = dn * v;
+        } else if (j < LDF) {
+            d[j] = 0.f;
+        }
+    }
+    if (lane == 0) coef[r] = -(dn * dn) * t;
+}
+
+struct EpiRowOuter {  // out[(b*Fr+m)*8+h][j] = acc + rowscale[row] * colvec[(b*8+h)][j]   (z = b*8+h); rowscale null -> 1
+    float* out;
+    const float* rowscale;
+    const float* colvec;
+    int Fr;
+    __device__ __forceinline__ float col(int) const { return 0.f; }
+    __device__ __forceinline__ void operator()(int z, int m, int j, float v, float) const {
+        const int b = z / H, h = z % H;
+        const int64_t row = ((int64_t)b * Fr + m) * H + h;
+        const float rs = rowscale ? rowscale[row] : 1.0f;
+        out[row * LDF + j] = fmaf(rs, colvec[(int64_t)z * LDF + j], v);
+    }
+};
+
+struct EpiAxpyRow {  // C[r][d] = acc + coef[r] * src[r][d]
+    float* C;
+    const float* coef;
+    const float* src;
+    int ld;
+    __device__ __forceinline__ float col(int) const { return 0.f; }
+    __device__ __forceinline__ void operator()(int, int m, int n, float v, float) const {
+        const int64_t o = (int64_t)m * ld + n;
+        C[o] = fmaf(coef[m], src[o], v);
+    }
+};
+
+struct EpiAccumulate {  // C += acc
+    float* C;
+    int64_t ldc;
+    __device__ __forceinline__ float col(int) const { return 0.f; }
+    __device__ __forceinline__ void operator()(int, int m, int n, float v, float) const { C[(int64_t)m * ldc + n] += v; }
+};
+
+// GroupNorm(4) + LeakyReLU backward.  Pass 1 (per utterance, group): s1 = sum dy*g, s2 = sum dy*g*xhat over 64 ch x Fr.
+__global__ void __launch_bounds__(256) groupnorm_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                  const float* __restrict__ dy, const float* __restrict__ stats,
+                                                                  const float* __restrict__ gamma, int Fr,
+                                                                  float* __restrict__ bstats) {
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int c = threadIdx.x & 63, fl = threadIdx.x >> 6;
+    const int ch = g * 64 + c;
+    const float mean = stats[(b * 4 + g) * 2], rstd = stats[(b * 4 + g) * 2 + 1];
+    const float ga = gamma[ch];
+    double s1 = 0.0, s2 = 0.0;
+    for (int f = fl; f < Fr; f += 4) {
+        const int64_t i = ((int64_t)b * Fr + f) * D + ch;
+        const float slope = y[i] > 0.f ? 1.0f : 0.01f;   // y = lrelu(gn(x)); sign(y) = sign(gn(x))
+        const float dgn = dy[i] * slope;
+        const float xh = (x[i] - mean) * rstd;
+        s1 += (double)(dgn * ga);
+        s2 += (double)(dgn * ga * xh);
+    }
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    __shared__ double red[8];
+    if ((threadIdx.x & 63) == 0) {
+        red[fl] = s1;
+        red[4 + fl] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double n = 64.0 * Fr;
+        bstats[(b * 4 + g) * 2 + 0] = (float)((red[0] + red[1] + red[2] + red[3]) / n);
+        bstats[(b * 4 + g) * 2 + 1] = (float)((red[4] + red[5] + red[6] + red[7]) / n);
+    }
+}
+
+// Pass 2: dx = rstd*(dgn*gamma - m1 - xhat*m2);  also gxh = dgn*xhat and dgn itself (for d gamma / d beta column sums)
+__global__ void __launch_bounds__(256) groupnorm_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                  const float* __restrict__ dy, const float* __restrict__ stats,
+                                                                  const float* __restrict__ bstats,
+                                                                  const float* __restrict__ gamma, int64_t rows, int Fr,
+                                                                  float* __restrict__ dx, float* __restrict__ gxh,
+                                                                  float* __restrict__ dgn_out) {
+    const int64_t total = rows * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / D;
+        const int ch = (int)(i % D);
+        const int b = (int)(m / Fr), g = ch >> 6;
+        const float mean = stats[(b * 4 + g) * 2], rstd = stats[(b * 4 + g) * 2 + 1];
+        const float m1 = bstats[(b * 4 + g) * 2], m2 = bstats[(b * 4 + g) * 2 + 1];
+        const float slope = y[i] > 0.f ? 1.0f : 0.01f;
+        const float dgn = dy[i] * slope;
+        const float xh = (x[i] - mean) * rstd;
+        dx[i] = rstd * (dgn * gamma[ch] - m1 - xh * m2);
+        gxh[i] = dgn * xh;
+        dgn_out[i] = dgn;
+    }
+}
+
+// shifted copy over the frame axis with zero fill at utterance edges: out[b,f,:] = x[b,f+shift,:]
+__global__ void __launch_bounds__(256) shift_rows_kernel(const float* __restrict__ x, int64_t rows, int Fr, int C, int shift,
+                                                         float* __restrict__ out) {
+    const int64_t total = rows * (C / 4);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / (C / 4);
+        const int c4 = (int)(i % (C / 4)) * 4;
+        const int f = (int)(m % Fr) + shift;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (f >= 0 && f < Fr) v = *(const f32x4*)(x + (m + shift) * C + c4);
+        *(f32x4*)(out + m * C + c4) = v;
+    }
+}
+
+// packed (Cout, 3, Cin) gradient -> torch layout (Cout, Cin, 3)
+__global__ void unpack_conv3_kernel(const float* __restrict__ packed, int Cout, int Cin, float* __restrict__ out) {
+    const int64_t total = (int64_t)Cout * Cin * 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % 3);
+        const int c = (int)((i / 3) % Cin);
+        const int o = (int)(i / (3 * Cin));
+        out[i] = packed[(int64_t)o * 3 * Cin + (int64_t)tap * Cin + c];
+    }
+}
+
+// conv weight (Cout, Cin, 3) -> transposed-conv operand (Cin, 3*Cout): out[c][tap*Cout + o] = w[o][c][2 - tap]
+__global__ void pack_conv3_transposed_kernel(const float* __restrict__ w, int Cout, int Cin, float* __restrict__ out) {
+    const int64_t total = (int64_t)Cout * Cin * 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % 3);
+        const int c = (int)((i / 3) % Cin);
+        const int o = (int)(i / (3 * Cin));
+        out[(int64_t)c * 3 * Cout + (int64_t)(2 - tap) * Cout + o] = w[i];
+    }
+}
+
+// weight-norm backward, one wave per output row: W = g*v/|v|  ->  d_g = (dW . v)/|v|,  d_v = g/|v| * (dW - (dW.vhat) vhat)
+__global__ void __launch_bounds__(256) weight_norm_bwd_kernel(const float* __restrict__ g, const float* __restrict__ v,
+                                                              const float* __restrict__ dW, int n_out, int n_in,
+                                                              float* __restrict__ dg, float* __restrict__ dv) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= n_out) return;
+    const float* vr = v + (int64_t)o * n_in;
+    const float* dr = dW + (int64_t)o * n_in;
+    float ss = 0.f, dot = 0.f;
+    for (int i = lane; i < n_in; i += 64) {
+        ss = fmaf(vr[i], vr[i], ss);
+        dot = fmaf(dr[i], vr[i], dot);
+    }
+    ss = wave_sum(ss);
+    dot = wave_sum(dot);
+    const float nrm = sqrtf(ss);
+    if (lane == 0) dg[o] = dot / nrm;
+    const float s = g[o] / nrm, proj = dot / ss;
+    for (int i = lane; i < n_in; i += 64) dv[(int64_t)o * n_in + i] = s * (dr[i] - proj * vr[i]);
+}
+
+// speaker-embedding gradient: table is zeroed by the caller; per utterance the frame-summed d_x row is added to its
+// speaker's row (atomics: several utterances may share a speaker), or w_k * (sum over everything) in mix mode
+__global__ void __launch_bounds__(256) spk_embed_bwd_kernel(const float* __restrict__ dx, int64_t B, int Fr,
+                                                            const int64_t* __restrict__ spk_id, int64_t n_spk_id,
+                                                            MixArgs mix, float* __restrict__ dtable) {
+    const int c = threadIdx.x;  // D == 256 channels
+    const int64_t b = blockIdx.x;
+    float s = 0.f;
+    for (int f = 0; f < Fr; ++f) s += dx[((int64_t)b * Fr + f) * D + c];
+    if (mix.n > 0) {
+        for (int k = 0; k < mix.n; ++k) atomicAdd(dtable + (mix.ids[k] - 1) * D + c, mix.w[k] * s);
+    } else {
+        const int64_t id = spk_id[n_spk_id == 1 ? 0 : b];
+        atomicAdd(dtable + (id - 1) * D + c, s);
     }
 }
 
@@ -297,177 +694,207 @@ inline unsigned grid_for(int64_t total, int per_block = 256, int cap = 8192) {
     return (unsigned)g;
 }
 
-}  // namespace
+// ---- buffers of one forward pass --------------------------------------------------------------------------------
+// Inference aliases the three layers onto one set and updates the residual stream in place; training keeps every
+// activation the adjoints need (about 38 KB per frame and layer).
+struct LayerBufs {
+    float *x_in, *y, *q, *k, *v, *qf, *kf, *ks, *cx, *dinv, *attn, *x_mid, *y2, *g1, *glu, *pre, *dwo, *x_out;
+};
+struct U2CBufs {
+    float *w1, *w2, *wh, *t1, *t2, *gst, *y_final;
+    LayerBufs l[3];
+};
 
-extern "C" int ddsp_unit2ctrl_fwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_weights* wp, const float* units,
-                                  const float* f0_frames, const float* phase_frames, const float* volume,
-                                  const int64_t* spk_id, int64_t n_spk_id, const int64_t* mix_ids_host,
-                                  const float* mix_w_host, int n_mix, int64_t B, int64_t Fr, float* ctrl) {
-    DDSP_REQUIRE(ctx, ctx && wp && units && f0_frames && phase_frames && volume && ctrl, "ddsp_unit2ctrl_fwd: null argument");
-    DDSP_REQUIRE(ctx, B >= 0 && Fr >= 1 && B * Fr < (1 << 26), "ddsp_unit2ctrl_fwd: bad shape");
-    DDSP_REQUIRE(ctx, n_mix >= 0 && n_mix <= 16, "ddsp_unit2ctrl_fwd: at most 16 mixed speakers");
-    DDSP_REQUIRE(ctx, n_mix > 0 || (spk_id && (n_spk_id == 1 || n_spk_id == B)), "ddsp_unit2ctrl_fwd: spk_id must hold 1 or B ids");
-    DDSP_REQUIRE(ctx, n_mix == 0 || (mix_ids_host && mix_w_host), "ddsp_unit2ctrl_fwd: mix arrays missing");
-    const ddsp_u2c_weights w = *wp;
-    DDSP_REQUIRE(ctx, w.n_unit >= 4 && w.n_unit % 4 == 0 && w.n_out >= 1 && w.n_spk >= 1, "ddsp_unit2ctrl_fwd: bad widths");
-    for (int k = 0; k < n_mix; ++k)
-        DDSP_REQUIRE(ctx, mix_ids_host[k] >= 1 && mix_ids_host[k] <= w.n_spk, "ddsp_unit2ctrl_fwd: mixed speaker id out of range");
-    if (B == 0) return DDSP_OK;
-    hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
-    const int64_t M = B * Fr, M8 = M * H;
-    const int iM = (int)M;
-
-    // ---- scratch plan (floats) ----
-    const size_t n_w1 = (size_t)D * 3 * w.n_unit, n_w2 = (size_t)D * 3 * D, n_wh = (size_t)w.n_out * D;
-    const size_t plan[] = {n_w1, n_w2, n_wh,
-                           (size_t)M * D,       // t1
-                           (size_t)M * D,       // t2
-                           (size_t)M * D,       // x
-                           (size_t)M * D,       // y
-                           (size_t)M * INNER,   // q
-                           (size_t)M * INNER,   // k
-                           (size_t)M * INNER,   // v
-                           (size_t)M8 * LDF,    // qf
-                           (size_t)M8 * LDF,    // kf
-                           (size_t)B * H * LDF, // ks
-                           (size_t)B * H * NF * DH,  // ctx
-                           (size_t)M8,          // dinv
-                           (size_t)M * INNER,   // attn
-                           (size_t)M * 2 * INNER,  // g1
-                           (size_t)B * 4 * 2};  // gn stats
-    size_t total = 0;
-    for (size_t s : plan) total += ((s * sizeof(float) + 255) & ~(size_t)255) + 256;
-    int rc = ddsp_scratch_reserve_bytes(ctx, total);
-    if (rc) return rc;
-    ddsp_scratch_reset(ctx);
-    float* buf[sizeof(plan) / sizeof(plan[0])];
-    for (size_t i = 0; i < sizeof(plan) / sizeof(plan[0]); ++i) {
-        rc = ddsp_scratch_get(ctx, plan[i] * sizeof(float), (void**)&buf[i]);
-        if (rc) return rc;
+struct Arena {  // sizes first (dry run), then pointers
+    ddsp_ctx* ctx;
+    bool dry;
+    size_t total;
+    int rc;
+    float* get(size_t n_floats) {
+        const size_t bytes = ((n_floats * sizeof(float) + 255) & ~(size_t)255) + 256;
+        if (dry) {
+            total += bytes;
+            return nullptr;
+        }
+        void* p = nullptr;
+        const int r = ddsp_scratch_get(ctx, n_floats * sizeof(float), &p);
+        if (r) rc = r;
+        return (float*)p;
     }
-    float *w1 = buf[0], *w2 = buf[1], *wh = buf[2], *t1 = buf[3], *t2 = buf[4], *x = buf[5], *y = buf[6], *q = buf[7],
-          *k = buf[8], *v = buf[9], *qf = buf[10], *kf = buf[11], *ks = buf[12], *cx = buf[13], *dinv = buf[14],
-          *attn = buf[15], *g1 = buf[16], *gst = buf[17];
-    float* glu = q;  // q/k are dead once the attention output exists
-    float* dw = k;
+};
 
-    // ---- weight preparation ----
+static void plan_forward(Arena& a, U2CBufs& bf, const ddsp_u2c_weights& w, int64_t B, int64_t Fr, bool keep) {
+    const size_t M = (size_t)(B * Fr), M8 = M * H;
+    bf.w1 = a.get((size_t)D * 3 * w.n_unit);
+    bf.w2 = a.get((size_t)D * 3 * D);
+    bf.wh = a.get((size_t)w.n_out * D);
+    bf.t1 = a.get(M * D);
+    bf.t2 = a.get(M * D);
+    bf.gst = a.get((size_t)B * 4 * 2);
+    bf.y_final = a.get(M * D);
+    auto one = [&](LayerBufs& L, float* x_in) {
+        L.x_in = x_in;
+        L.y = a.get(M * D);
+        L.q = a.get(M * INNER);
+        L.k = a.get(M * INNER);
+        L.v = a.get(M * INNER);
+        L.qf = a.get(M8 * LDF);
+        L.kf = a.get(M8 * LDF);
+        L.ks = a.get((size_t)B * H * LDF);
+        L.cx = a.get((size_t)B * H * NF * DH);
+        L.dinv = a.get(M8);
+        L.attn = a.get(M * INNER);
+        L.g1 = a.get(M * 2 * INNER);
+        if (keep) {
+            L.x_mid = a.get(M * D);
+            L.y2 = a.get(M * D);
+            L.glu = a.get(M * INNER);
+            L.pre = a.get(M * INNER);
+            L.dwo = a.get(M * INNER);
+            L.x_out = a.get(M * D);
+        } else {
+            L.x_mid = L.x_in;  // residuals in place
+            L.x_out = L.x_in;
+            L.y2 = L.y;
+            L.glu = L.q;       // q / k are dead once the attention output exists
+            L.dwo = L.k;
+            L.pre = nullptr;
+        }
+    };
+    float* x0 = a.get(M * D);
+    one(bf.l[0], x0);
+    if (keep) {
+        one(bf.l[1], bf.l[0].x_out);
+        one(bf.l[2], bf.l[1].x_out);
+    } else {
+        bf.l[1] = bf.l[0];
+        bf.l[2] = bf.l[0];
+    }
+}
+
+struct U2CInputs {
+    const float *units, *f0, *phase, *volume;
+    const int64_t* spk_id;
+    int64_t n_spk_id;
+    MixArgs mix;
+    int64_t B, Fr;
+};
+
+static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w, const U2CInputs& in, U2CBufs& bf,
+                       float* ctrl) {
+    const int64_t B = in.B, Fr = in.Fr, M = B * Fr, M8 = M * H;
+    const int iM = (int)M;
+    const size_t n_w1 = (size_t)D * 3 * w.n_unit, n_w2 = (size_t)D * 3 * D, n_wh = (size_t)w.n_out * D;
     PROF(PF_U2C_PREP, 0, 8.0 * (n_w1 + n_w2 + n_wh),
-         hipLaunchKernelGGL(pack_conv3_kernel, dim3(grid_for(n_w1)), dim3(256), 0, st, w.prenet_conv1_w, D, w.n_unit, w1);
-         hipLaunchKernelGGL(pack_conv3_kernel, dim3(grid_for(n_w2)), dim3(256), 0, st, w.prenet_conv2_w, D, D, w2);
-         hipLaunchKernelGGL(weight_norm_kernel, dim3((w.n_out + 3) / 4), dim3(256), 0, st, w.head_g, w.head_v, w.n_out, D, wh));
-
+         hipLaunchKernelGGL(pack_conv3_kernel, dim3(grid_for(n_w1)), dim3(256), 0, st, w.prenet_conv1_w, D, w.n_unit, bf.w1);
+         hipLaunchKernelGGL(pack_conv3_kernel, dim3(grid_for(n_w2)), dim3(256), 0, st, w.prenet_conv2_w, D, D, bf.w2);
+         hipLaunchKernelGGL(weight_norm_kernel, dim3((w.n_out + 3) / 4), dim3(256), 0, st, w.head_g, w.head_v, w.n_out, D, bf.wh));
     // ---- prenet: conv k3 -> GroupNorm(4) -> LeakyReLU -> conv k3 ----
     {
-        gemm::Args g = gemm::make(units, w.n_unit, w1, 3 * w.n_unit, iM, D, 3 * w.n_unit);
+        gemm::Args g = gemm::make(in.units, w.n_unit, bf.w1, 3 * w.n_unit, iM, D, 3 * w.n_unit);
         g.Fr = (int)Fr;
         g.Cin = w.n_unit;
-        gemm::EpiStore e{t1, D, w.prenet_conv1_b, 1, 0, 0};
+        gemm::EpiStore e{bf.t1, D, w.prenet_conv1_b, 1, 0, 0};
         PROF(PF_U2C_GEMM_CONV3, 2.0 * M * D * 3 * w.n_unit, 4.0 * M * (w.n_unit + D),
              (gemm::launch<true, true, gemm::A_CONV3>(st, g, 1, e)));
     }
     PROF(PF_U2C_ROWWISE, 0, 4.0 * M * D,
-         hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(4, (unsigned)B), dim3(256), 0, st, t1, (int)Fr, gst));
+         hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(4, (unsigned)B), dim3(256), 0, st, bf.t1, (int)Fr, bf.gst));
     PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
-         hipLaunchKernelGGL(groupnorm_lrelu_kernel, dim3(grid_for(M * (D / 4))), dim3(256), 0, st, t1, gst,
-                            w.prenet_gn_w, w.prenet_gn_b, M, (int)Fr, t2));
+         hipLaunchKernelGGL(groupnorm_lrelu_kernel, dim3(grid_for(M * (D / 4))), dim3(256), 0, st, bf.t1, bf.gst,
+                            w.prenet_gn_w, w.prenet_gn_b, M, (int)Fr, bf.t2));
+    float* x = bf.l[0].x_in;
     {
-        gemm::Args g = gemm::make(t2, D, w2, 3 * D, iM, D, 3 * D);
+        gemm::Args g = gemm::make(bf.t2, D, bf.w2, 3 * D, iM, D, 3 * D);
         g.Fr = (int)Fr;
         g.Cin = D;
         gemm::EpiStore e{x, D, w.prenet_conv2_b, 1, 0, 0};
         PROF(PF_U2C_GEMM_CONV3, 2.0 * M * D * 3 * D, 8.0 * M * D, (gemm::launch<true, true, gemm::A_CONV3>(st, g, 1, e)));
     }
-    MixArgs mix;
-    mix.n = n_mix;
-    for (int i = 0; i < n_mix; ++i) {
-        mix.ids[i] = mix_ids_host[i];
-        mix.w[i] = mix_w_host[i];
-    }
     PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
-         hipLaunchKernelGGL(embed_add_kernel, dim3(grid_for(M * D)), dim3(256), 0, st, x, f0_frames, phase_frames, volume,
-                            w, spk_id, n_spk_id, mix, M, (int)Fr));
+         hipLaunchKernelGGL(embed_add_kernel, dim3(grid_for(M * D)), dim3(256), 0, st, x, in.f0, in.phase, in.volume, w,
+                            in.spk_id, in.n_spk_id, in.mix, M, (int)Fr));
     DDSP_LAUNCH_CHECK(ctx);
 
     const unsigned rows_g = (unsigned)ceil_div64(M, 4), rows8_g = (unsigned)ceil_div64(M8, 4);
     for (int l = 0; l < 3; ++l) {
         const ddsp_u2c_layer& L = w.layer[l];
-        // -- x += to_out(linear_attention(LN(x)))
+        LayerBufs& b = bf.l[l];
+        // -- x_mid = x_in + to_out(linear_attention(LN(x_in)))
         PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
-             hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, x, L.norm_w, L.norm_b, M, y));
+             hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, b.x_in, L.norm_w, L.norm_b, M, b.y));
         const float* pw[3] = {L.q_w, L.k_w, L.v_w};
         const float* pb[3] = {L.q_b, L.k_b, L.v_b};
-        float* po[3] = {q, k, v};
+        float* po[3] = {b.q, b.k, b.v};
         for (int i = 0; i < 3; ++i) {
-            gemm::Args g = gemm::make(y, D, pw[i], D, iM, INNER, D);
+            gemm::Args g = gemm::make(b.y, D, pw[i], D, iM, INNER, D);
             gemm::EpiStore e{po[i], INNER, pb[i], 1, 0, 0};
             PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * INNER * D, 4.0 * M * (D + INNER),
                  (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
         }
         {   // random-feature projections: (M*8, 64) x (266, 64)^T
-            gemm::Args g = gemm::make(q, DH, L.proj, DH, (int)M8, NF, DH);
-            gemm::EpiStore e{qf, LDF, nullptr, 1, 0, 0};
+            gemm::Args g = gemm::make(b.q, DH, L.proj, DH, (int)M8, NF, DH);
+            gemm::EpiStore e{b.qf, LDF, nullptr, 1, 0, 0};
             PROF(PF_U2C_GEMM_FEAT, 2.0 * M8 * NF * DH, 4.0 * M8 * (DH + NF),
                  (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
-            g.A = k;
-            e.C = kf;
+            g.A = b.k;
+            e.C = b.kf;
             PROF(PF_U2C_GEMM_FEAT, 2.0 * M8 * NF * DH, 4.0 * M8 * (DH + NF),
                  (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
         }
         PROF(PF_U2C_ROWWISE, 0, 4.0 * M8 * (2 * NF + DH),
-             hipLaunchKernelGGL(feature_map_kernel<true>, dim3(rows8_g), dim3(256), 0, st, qf, q, M8));
+             hipLaunchKernelGGL(feature_map_kernel<true>, dim3(rows8_g), dim3(256), 0, st, b.qf, b.q, M8));
         PROF(PF_U2C_ROWWISE, 0, 4.0 * M8 * (2 * NF + DH),
-             hipLaunchKernelGGL(feature_map_kernel<false>, dim3(rows8_g), dim3(256), 0, st, kf, k, M8));
+             hipLaunchKernelGGL(feature_map_kernel<false>, dim3(rows8_g), dim3(256), 0, st, b.kf, b.k, M8));
         PROF(PF_U2C_ROWWISE, 0, 4.0 * M8 * NF,
-             hipLaunchKernelGGL(key_sum_kernel, dim3((unsigned)(B * H)), dim3(320), 0, st, kf, (int)Fr, ks));
+             hipLaunchKernelGGL(key_sum_kernel, dim3((unsigned)(B * H)), dim3(320), 0, st, b.kf, (int)Fr, b.ks));
         {   // ctx[b,h] (266 x 64) = k'^T v : A stored [n][j] (K x M), B stored [n][e] (K x N)
-            gemm::Args g = gemm::make(kf, (int64_t)H * LDF, v, INNER, NF, DH, (int)Fr);
+            gemm::Args g = gemm::make(b.kf, (int64_t)H * LDF, b.v, INNER, NF, DH, (int)Fr);
             g.zdiv = H;
             g.sA_hi = (int64_t)Fr * H * LDF;
             g.sA_lo = LDF;
             g.sB_hi = (int64_t)Fr * INNER;
             g.sB_lo = DH;
-            gemm::EpiStore e{cx, DH, nullptr, 1, (int64_t)NF * DH, 0};
+            gemm::EpiStore e{b.cx, DH, nullptr, 1, (int64_t)NF * DH, 0};
             PROF(PF_U2C_GEMM_CTX, 2.0 * M8 * NF * DH, 4.0 * M8 * (NF + DH),
                  (gemm::launch_tile<64, 64, false, false, gemm::A_PLAIN>(st, g, (int)(B * H), e)));
         }
         PROF(PF_U2C_ROWWISE, 0, 4.0 * M8 * NF,
-             hipLaunchKernelGGL(attn_denominator_kernel, dim3(rows8_g), dim3(256), 0, st, qf, ks, (int)Fr, M8, dinv));
+             hipLaunchKernelGGL(attn_denominator_kernel, dim3(rows8_g), dim3(256), 0, st, b.qf, b.ks, (int)Fr, M8, b.dinv));
         {   // out[b,n,h,:] = dinv * (q'[b,n,h,:] ctx[b,h])
-            gemm::Args g = gemm::make(qf, (int64_t)H * LDF, cx, DH, (int)Fr, DH, NF);
+            gemm::Args g = gemm::make(b.qf, (int64_t)H * LDF, b.cx, DH, (int)Fr, DH, NF);
             g.zdiv = H;
             g.sA_hi = (int64_t)Fr * H * LDF;
             g.sA_lo = LDF;
             g.sB_hi = (int64_t)H * NF * DH;
             g.sB_lo = (int64_t)NF * DH;
-            EpiAttnOut e{attn, dinv, (int)Fr};
+            EpiAttnOut e{b.attn, b.dinv, (int)Fr};
             PROF(PF_U2C_GEMM_ATTNOUT, 2.0 * M8 * NF * DH, 4.0 * M8 * (NF + DH),
                  (gemm::launch_tile<64, 64, true, false, gemm::A_PLAIN>(st, g, (int)(B * H), e)));
         }
         {
-            gemm::Args g = gemm::make(attn, INNER, L.out_w, INNER, iM, D, INNER);
-            gemm::EpiResidual e{x, x, D, L.out_b};
+            gemm::Args g = gemm::make(b.attn, INNER, L.out_w, INNER, iM, D, INNER);
+            gemm::EpiResidual e{b.x_mid, b.x_in, D, L.out_b};
             PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * D * INNER, 4.0 * M * (INNER + 2 * D),
                  (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
         }
-        // -- x += conv_module(x)
+        // -- x_out = x_mid + conv_module(x_mid)
         PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
-             hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, x, L.cm_ln_w, L.cm_ln_b, M, y));
+             hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, b.x_mid, L.cm_ln_w, L.cm_ln_b, M, b.y2));
         {
-            gemm::Args g = gemm::make(y, D, L.cm_pw1_w, D, iM, 2 * INNER, D);
-            gemm::EpiStore e{g1, 2 * INNER, L.cm_pw1_b, 1, 0, 0};
+            gemm::Args g = gemm::make(b.y2, D, L.cm_pw1_w, D, iM, 2 * INNER, D);
+            gemm::EpiStore e{b.g1, 2 * INNER, L.cm_pw1_b, 1, 0, 0};
             PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * 2 * INNER * D, 4.0 * M * (D + 2 * INNER),
                  (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
         }
         PROF(PF_U2C_ROWWISE, 0, 12.0 * M * INNER,
-             hipLaunchKernelGGL(glu_kernel, dim3(grid_for(M * (INNER / 4))), dim3(256), 0, st, g1, M, glu));
+             hipLaunchKernelGGL(glu_kernel, dim3(grid_for(M * (INNER / 4))), dim3(256), 0, st, b.g1, M, b.glu));
         PROF(PF_U2C_ROWWISE, 2.0 * M * INNER * DWK, 8.0 * M * INNER,
-             hipLaunchKernelGGL(dwconv_silu_kernel, dim3(INNER / 256, (unsigned)(B * ((Fr + DW_RUN - 1) / DW_RUN))),
-                                dim3(256), 0, st, glu, L.cm_dw_w, L.cm_dw_b, (int)B, (int)Fr, dw));
+             hipLaunchKernelGGL((dwconv_kernel<true, false>), dim3(INNER / 256, (unsigned)(B * ((Fr + DW_RUN - 1) / DW_RUN))),
+                                dim3(256), 0, st, b.glu, L.cm_dw_w, L.cm_dw_b, (int)B, (int)Fr, b.dwo, b.pre));
         {
-            gemm::Args g = gemm::make(dw, INNER, L.cm_pw2_w, INNER, iM, D, INNER);
-            gemm::EpiResidual e{x, x, D, L.cm_pw2_b};
+            gemm::Args g = gemm::make(b.dwo, INNER, L.cm_pw2_w, INNER, iM, D, INNER);
+            gemm::EpiResidual e{b.x_out, b.x_mid, D, L.cm_pw2_b};
             PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * D * INNER, 4.0 * M * (INNER + 2 * D),
                  (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
         }
@@ -475,13 +902,350 @@ extern "C" int ddsp_unit2ctrl_fwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
     }
     // ---- LayerNorm -> weight-normed head ----
     PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
-         hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, x, w.final_ln_w, w.final_ln_b, M, y));
+         hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, bf.l[2].x_out, w.final_ln_w, w.final_ln_b,
+                            M, bf.y_final));
     {
-        gemm::Args g = gemm::make(y, D, wh, D, iM, w.n_out, D);
+        gemm::Args g = gemm::make(bf.y_final, D, bf.wh, D, iM, w.n_out, D);
         gemm::EpiStore e{ctrl, w.n_out, w.head_b, 1, 0, 0};
         PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * w.n_out * D, 4.0 * M * (D + w.n_out),
              (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
     }
     DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}
+
+static int check_inputs(ddsp_ctx* ctx, const ddsp_u2c_weights* wp, const float* units, const float* f0_frames,
+                        const float* phase_frames, const float* volume, const int64_t* spk_id, int64_t n_spk_id,
+                        const int64_t* mix_ids_host, const float* mix_w_host, int n_mix, int64_t B, int64_t Fr,
+                        U2CInputs& in) {
+    DDSP_REQUIRE(ctx, ctx && wp && units && f0_frames && phase_frames && volume, "ddsp_unit2ctrl: null argument");
+    DDSP_REQUIRE(ctx, B >= 0 && Fr >= 1 && B * Fr < (1 << 26), "ddsp_unit2ctrl: bad shape");
+    DDSP_REQUIRE(ctx, n_mix >= 0 && n_mix <= 16, "ddsp_unit2ctrl: at most 16 mixed speakers");
+    DDSP_REQUIRE(ctx, n_mix > 0 || (spk_id && (n_spk_id == 1 || n_spk_id == B)), "ddsp_unit2ctrl: spk_id must hold 1 or B ids");
+    DDSP_REQUIRE(ctx, n_mix == 0 || (mix_ids_host && mix_w_host), "ddsp_unit2ctrl: mix arrays missing");
+    DDSP_REQUIRE(ctx, wp->n_unit >= 4 && wp->n_unit % 4 == 0 && wp->n_out >= 1 && wp->n_spk >= 1, "ddsp_unit2ctrl: bad widths");
+    for (int k = 0; k < n_mix; ++k)
+        DDSP_REQUIRE(ctx, mix_ids_host[k] >= 1 && mix_ids_host[k] <= wp->n_spk, "ddsp_unit2ctrl: mixed speaker id out of range");
+    in.units = units;
+    in.f0 = f0_frames;
+    in.phase = phase_frames;
+    in.volume = volume;
+    in.spk_id = spk_id;
+    in.n_spk_id = n_spk_id;
+    in.mix.n = n_mix;
+    for (int i = 0; i < n_mix; ++i) {
+        in.mix.ids[i] = mix_ids_host[i];
+        in.mix.w[i] = mix_w_host[i];
+    }
+    in.B = B;
+    in.Fr = Fr;
+    return DDSP_OK;
+}
+
+// ---- helpers of the backward pass ------------------------------------------------------------------------------
+// out[o*ldo + coff + c] = sum_m dY[m][o] * X[m][c]   (split-K batches on the matrix pipe + one reduction)
+static int wgrad(ddsp_ctx* ctx, hipStream_t st, const float* dY, int64_t ldy, int O, const float* X, int64_t ldx, int C,
+                 int64_t M, float* partial, float* out, int64_t ldo, int coff);
+__global__ void __launch_bounds__(256) reduce_partials_2d_kernel(const float* __restrict__ partial, int nz, int O, int C,
+                                                                 float* __restrict__ out, int64_t ldo, int coff) {
+    const int64_t n = (int64_t)O * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < nz; ++z) s += partial[(int64_t)z * n + i];
+        out[(i / C) * ldo + coff + (i % C)] = s;
+    }
+}
+constexpr int WG_SPLITS = 16;
+static int wgrad(ddsp_ctx* ctx, hipStream_t st, const float* dY, int64_t ldy, int O, const float* X, int64_t ldx, int C,
+                 int64_t M, float* partial, float* out, int64_t ldo, int coff) {
+    int64_t chunk = (M + WG_SPLITS - 1) / WG_SPLITS;
+    chunk = (chunk + 31) & ~(int64_t)31;
+    const int nfull = (int)(M / chunk);
+    const int64_t tail = M - (int64_t)nfull * chunk;
+    ddsp_prof_begin(ctx, st, PF_U2C_BWD);
+    if (nfull > 0) {
+        gemm::Args g = gemm::make(dY, ldy, X, ldx, O, C, (int)chunk);
+        g.sA_hi = chunk * ldy;
+        g.sB_hi = chunk * ldx;
+        gemm::EpiStore e{partial, C, nullptr, 1, (int64_t)O * C, 0};
+        gemm::launch_tile<64, 64, false, false, gemm::A_PLAIN>(st, g, nfull, e);
+    }
+    if (tail > 0) {
+        gemm::Args g = gemm::make(dY + (int64_t)nfull * chunk * ldy, ldy, X + (int64_t)nfull * chunk * ldx, ldx, O, C, (int)tail);
+        gemm::EpiStore e{partial + (int64_t)nfull * O * C, C, nullptr, 1, 0, 0};
+        gemm::launch_tile<64, 64, false, false, gemm::A_PLAIN>(st, g, 1, e);
+    }
+    hipLaunchKernelGGL(reduce_partials_2d_kernel, dim3(grid_for((int64_t)O * C)), dim3(256), 0, st, partial,
+                       nfull + (tail > 0 ? 1 : 0), O, C, out, ldo, coff);
+    ddsp_prof_end(ctx, st, 2.0 * M * O * (double)C, 4.0 * M * (O + C));
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}
+
+// out[c] = sum_r X[r][c] * w(r)
+static int colsum(ddsp_ctx* ctx, hipStream_t st, const float* X, int64_t ld, int64_t rows, int cols, const float* wsrc,
+                  int wmode, float* partial, float* out) {
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, CS_CHUNKS), dim3(256), 0, st, X, ld, rows, cols, wsrc,
+                       wmode, partial);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(cols)), dim3(256), 0, st, partial, CS_CHUNKS, (int64_t)cols, out);
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}
+
+// dX[m][c] = sum_o dY[m][o] * W[o][c]   (W stored (O, C) like nn.Linear.weight), optionally accumulated into dX
+static void dgrad(hipStream_t st, const float* dY, int64_t ldy, const float* W, int O, int C, int64_t M, float* dX,
+                  bool accumulate) {
+    gemm::Args g = gemm::make(dY, ldy, W, C, (int)M, C, O);
+    if (accumulate) {
+        EpiAccumulate e{dX, C};
+        gemm::launch<true, false, gemm::A_PLAIN>(st, g, 1, e);
+    } else {
+        gemm::EpiStore e{dX, C, nullptr, 1, 0, 0};
+        gemm::launch<true, false, gemm::A_PLAIN>(st, g, 1, e);
+    }
+}
+
+}  // namespace
+
+extern "C" int ddsp_unit2ctrl_fwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_weights* wp, const float* units,
+                                  const float* f0_frames, const float* phase_frames, const float* volume,
+                                  const int64_t* spk_id, int64_t n_spk_id, const int64_t* mix_ids_host,
+                                  const float* mix_w_host, int n_mix, int64_t B, int64_t Fr, float* ctrl) {
+    U2CInputs in;
+    int rc = check_inputs(ctx, wp, units, f0_frames, phase_frames, volume, spk_id, n_spk_id, mix_ids_host, mix_w_host,
+                          n_mix, B, Fr, in);
+    if (rc) return rc;
+    DDSP_REQUIRE(ctx, ctrl, "ddsp_unit2ctrl_fwd: null ctrl");
+    if (B == 0) return DDSP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    const ddsp_u2c_weights w = *wp;
+    U2CBufs bf;
+    Arena dry{ctx, true, 0, 0};
+    plan_forward(dry, bf, w, B, Fr, false);
+    rc = ddsp_scratch_reserve_bytes(ctx, dry.total + 4096);
+    if (rc) return rc;
+    ddsp_scratch_reset(ctx);
+    Arena a{ctx, false, 0, 0};
+    plan_forward(a, bf, w, B, Fr, false);
+    if (a.rc) return a.rc;
+    return u2c_forward(ctx, st, w, in, bf, ctrl);
+}
+
+extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_weights* wp, const float* units,
+                                  const float* f0_frames, const float* phase_frames, const float* volume,
+                                  const int64_t* spk_id, int64_t n_spk_id, const int64_t* mix_ids_host,
+                                  const float* mix_w_host, int n_mix, int64_t B, int64_t Fr, const float* d_ctrl,
+                                  const ddsp_u2c_weights* grads_host, float* ctrl_out) {
+    U2CInputs in;
+    int rc = check_inputs(ctx, wp, units, f0_frames, phase_frames, volume, spk_id, n_spk_id, mix_ids_host, mix_w_host,
+                          n_mix, B, Fr, in);
+    if (rc) return rc;
+    DDSP_REQUIRE(ctx, d_ctrl && grads_host, "ddsp_unit2ctrl_bwd: null argument");
+    if (B == 0) return DDSP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    const ddsp_u2c_weights w = *wp;
+    const ddsp_u2c_weights gr = *grads_host;  // same layout; the pointers are written through
+#define G(p) const_cast<float*>(gr.p)
+    const int64_t M = B * Fr, M8 = M * H;
+    const int NO = w.n_out;
+
+    // ---- arena: kept forward activations + backward temporaries ----
+    U2CBufs bf;
+    float *ctrl, *dX, *dA, *dB512, *dC512, *dV512, *dG1, *dQF, *dKF, *dcx, *dks, *dD, *coefq, *coefk, *gx, *wpart, *cpart,
+        *dWh, *pk, *xs, *dwpart, *gbst, *w2t;
+    auto plan_bwd = [&](Arena& a) {
+        plan_forward(a, bf, w, B, Fr, true);
+        ctrl = a.get((size_t)M * NO);
+        dX = a.get((size_t)M * D);          // gradient on the residual stream
+        dA = a.get((size_t)M * D);          // second stream-sized temporary
+        dB512 = a.get((size_t)M * INNER);   // d_dwo / d_pre / d_attn->d_num / d_q
+        dC512 = a.get((size_t)M * INNER);   // d_glu / d_k
+        dV512 = a.get((size_t)M * INNER);   // d_v
+        dG1 = a.get((size_t)M * 2 * INNER);
+        dQF = a.get((size_t)M8 * LDF);
+        dKF = a.get((size_t)M8 * LDF);
+        dcx = a.get((size_t)B * H * NF * DH);
+        dks = a.get((size_t)B * H * LDF);
+        dD = a.get((size_t)M8);
+        coefq = a.get((size_t)M8);
+        coefk = a.get((size_t)M8);
+        gx = a.get((size_t)M * D);
+        const size_t omax = (size_t)(NO > 2 * INNER ? NO : 2 * INNER);
+        wpart = a.get((size_t)(WG_SPLITS + 1) * omax * (size_t)(w.n_unit > INNER ? w.n_unit : INNER));
+        cpart = a.get((size_t)CS_CHUNKS * (omax > 2048 ? omax : 2048));
+        dWh = a.get((size_t)NO * D);
+        pk = a.get((size_t)D * 3 * (w.n_unit > D ? w.n_unit : D));
+        xs = a.get((size_t)M * (w.n_unit > D ? w.n_unit : D));
+        dwpart = a.get((size_t)B * INNER * DWK);
+        gbst = a.get((size_t)B * 4 * 2);
+        w2t = a.get((size_t)D * 3 * D);
+    };
+    Arena dry{ctx, true, 0, 0};
+    plan_bwd(dry);
+    rc = ddsp_scratch_reserve_bytes(ctx, dry.total + 4096);
+    if (rc) return rc;
+    ddsp_scratch_reset(ctx);
+    Arena a{ctx, false, 0, 0};
+    plan_bwd(a);
+    if (a.rc) return a.rc;
+
+    rc = u2c_forward(ctx, st, w, in, bf, ctrl);
+    if (rc) return rc;
+    if (ctrl_out) DDSP_HIP(ctx, hipMemcpyAsync(ctrl_out, ctrl, (size_t)M * NO * sizeof(float), hipMemcpyDeviceToDevice, st));
+
+    const unsigned rows_g = (unsigned)ceil_div64(M, 4), rows8_g = (unsigned)ceil_div64(M8, 4);
+    // ---- head: ctrl = LN(x) W^T + b, W = g v/|v| ----
+    if ((rc = wgrad(ctx, st, d_ctrl, NO, NO, bf.y_final, D, D, M, wpart, dWh, D, 0))) return rc;
+    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((NO + 3) / 4), dim3(256), 0, st, w.head_g, w.head_v, dWh, NO, D,
+                       G(head_g), G(head_v));
+    if ((rc = colsum(ctx, st, d_ctrl, NO, M, NO, nullptr, 0, cpart, G(head_b)))) return rc;
+    dgrad(st, d_ctrl, NO, bf.wh, NO, D, M, dA, false);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(rows_g), dim3(256), 0, st, bf.l[2].x_out, w.final_ln_w, dA, nullptr, M, dX, gx);
+    if ((rc = colsum(ctx, st, gx, D, M, D, nullptr, 0, cpart, G(final_ln_w)))) return rc;
+    if ((rc = colsum(ctx, st, dA, D, M, D, nullptr, 0, cpart, G(final_ln_b)))) return rc;
+
+    for (int l = 2; l >= 0; --l) {
+        const ddsp_u2c_layer& L = w.layer[l];
+        const ddsp_u2c_layer& GL = gr.layer[l];
+        LayerBufs& b = bf.l[l];
+#define GLP(p) const_cast<float*>(GL.p)
+        // ===== conv module: x_out = x_mid + pw2(silu(dw(glu(pw1(LN(x_mid)))))) =====
+        if ((rc = wgrad(ctx, st, dX, D, D, b.dwo, INNER, INNER, M, wpart, GLP(cm_pw2_w), INNER, 0))) return rc;
+        if ((rc = colsum(ctx, st, dX, D, M, D, nullptr, 0, cpart, GLP(cm_pw2_b)))) return rc;
+        dgrad(st, dX, D, L.cm_pw2_w, D, INNER, M, dB512, false);                                   // d_dwo
+        hipLaunchKernelGGL(silu_bwd_kernel, dim3(grid_for(M * INNER)), dim3(256), 0, st, b.pre, dB512, M * INNER, dB512);  // d_pre
+        hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(INNER / 64, (unsigned)B), dim3(256), 0, st, dB512, b.glu, (int)Fr, dwpart);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(INNER * DWK)), dim3(256), 0, st, dwpart, (int)B,
+                           (int64_t)INNER * DWK, GLP(cm_dw_w));
+        if ((rc = colsum(ctx, st, dB512, INNER, M, INNER, nullptr, 0, cpart, GLP(cm_dw_b)))) return rc;
+        hipLaunchKernelGGL((dwconv_kernel<false, true>), dim3(INNER / 256, (unsigned)(B * ((Fr + DW_RUN - 1) / DW_RUN))),
+                           dim3(256), 0, st, dB512, L.cm_dw_w, nullptr, (int)B, (int)Fr, dC512, nullptr);   // d_glu
+        hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for(M * INNER)), dim3(256), 0, st, b.g1, dC512, M, dG1);
+        if ((rc = wgrad(ctx, st, dG1, 2 * INNER, 2 * INNER, b.y2, D, D, M, wpart, GLP(cm_pw1_w), D, 0))) return rc;
+        if ((rc = colsum(ctx, st, dG1, 2 * INNER, M, 2 * INNER, nullptr, 0, cpart, GLP(cm_pw1_b)))) return rc;
+        dgrad(st, dG1, 2 * INNER, L.cm_pw1_w, 2 * INNER, D, M, dA, false);                         // d_y2
+        hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(rows_g), dim3(256), 0, st, b.x_mid, L.cm_ln_w, dA, dX, M, dX, gx);
+        if ((rc = colsum(ctx, st, gx, D, M, D, nullptr, 0, cpart, GLP(cm_ln_w)))) return rc;
+        if ((rc = colsum(ctx, st, dA, D, M, D, nullptr, 0, cpart, GLP(cm_ln_b)))) return rc;
+        // dX now holds d x_mid
+
+        // ===== attention: x_mid = x_in + to_out(attn) =====
+        if ((rc = wgrad(ctx, st, dX, D, D, b.attn, INNER, INNER, M, wpart, GLP(out_w), INNER, 0))) return rc;
+        if ((rc = colsum(ctx, st, dX, D, M, D, nullptr, 0, cpart, GLP(out_b)))) return rc;
+        dgrad(st, dX, D, L.out_w, D, INNER, M, dB512, false);                                       // d_attn
+        hipLaunchKernelGGL(attn_out_bwd_kernel, dim3(rows8_g), dim3(256), 0, st, dB512, b.attn, b.dinv, M8, dD);  // d_num, d_D
+        {   // d_q' = d_num ctx^T + d_D ks^T
+            gemm::Args g = gemm::make(dB512, INNER, b.cx, DH, (int)Fr, NF, DH);
+            g.zdiv = H;
+            g.sA_hi = (int64_t)Fr * INNER;
+            g.sA_lo = DH;
+            g.sB_hi = (int64_t)H * NF * DH;
+            g.sB_lo = (int64_t)NF * DH;
+            EpiRowOuter e{dQF, dD, b.ks, (int)Fr};
+            gemm::launch_tile<64, 64, true, true, gemm::A_PLAIN>(st, g, (int)(B * H), e);
+        }
+        {   // d_ctx = q'^T d_num
+            gemm::Args g = gemm::make(b.qf, (int64_t)H * LDF, dB512, INNER, NF, DH, (int)Fr);
+            g.zdiv = H;
+            g.sA_hi = (int64_t)Fr * H * LDF;
+            g.sA_lo = LDF;
+            g.sB_hi = (int64_t)Fr * INNER;
+            g.sB_lo = DH;
+            gemm::EpiStore e{dcx, DH, nullptr, 1, (int64_t)NF * DH, 0};
+            gemm::launch_tile<64, 64, false, false, gemm::A_PLAIN>(st, g, (int)(B * H), e);
+        }
+        hipLaunchKernelGGL(weighted_key_sum_kernel, dim3((unsigned)(B * H)), dim3(320), 0, st, b.qf, dD, (int)Fr, dks);
+        {   // d_k' = v d_ctx^T + d_ks^T
+            gemm::Args g = gemm::make(b.v, INNER, dcx, DH, (int)Fr, NF, DH);
+            g.zdiv = H;
+            g.sA_hi = (int64_t)Fr * INNER;
+            g.sA_lo = DH;
+            g.sB_hi = (int64_t)H * NF * DH;
+            g.sB_lo = (int64_t)NF * DH;
+            EpiRowOuter e{dKF, nullptr, dks, (int)Fr};
+            gemm::launch_tile<64, 64, true, true, gemm::A_PLAIN>(st, g, (int)(B * H), e);
+        }
+        {   // d_v = k' d_ctx
+            gemm::Args g = gemm::make(b.kf, (int64_t)H * LDF, dcx, DH, (int)Fr, DH, NF);
+            g.zdiv = H;
+            g.sA_hi = (int64_t)Fr * H * LDF;
+            g.sA_lo = LDF;
+            g.sB_hi = (int64_t)H * NF * DH;
+            g.sB_lo = (int64_t)NF * DH;
+            EpiAttnOut e{dV512, nullptr, (int)Fr};
+            gemm::launch_tile<64, 64, true, false, gemm::A_PLAIN>(st, g, (int)(B * H), e);
+        }
+        hipLaunchKernelGGL(feature_map_bwd_kernel<true>, dim3(rows8_g), dim3(256), 0, st, b.qf, dQF, M8, coefq);
+        hipLaunchKernelGGL(feature_map_bwd_kernel<false>, dim3(rows8_g), dim3(256), 0, st, b.kf, dKF, M8, coefk);
+        {   // d_q = d_raw_q P + coef_q q   (rows = (frame, head), 64 columns == the (M, 512) layout of q)
+            gemm::Args g = gemm::make(dQF, LDF, L.proj, DH, (int)M8, DH, NF);
+            EpiAxpyRow e{dB512, coefq, b.q, DH};
+            gemm::launch<true, false, gemm::A_PLAIN>(st, g, 1, e);
+            g.A = dKF;
+            EpiAxpyRow e2{dC512, coefk, b.k, DH};
+            gemm::launch<true, false, gemm::A_PLAIN>(st, g, 1, e2);
+        }
+        DDSP_LAUNCH_CHECK(ctx);
+        const float* dqkv[3] = {dB512, dC512, dV512};
+        const float* pw[3] = {L.q_w, L.k_w, L.v_w};
+        float* gw[3] = {GLP(q_w), GLP(k_w), GLP(v_w)};
+        float* gb[3] = {GLP(q_b), GLP(k_b), GLP(v_b)};
+        for (int i = 0; i < 3; ++i) {
+            if ((rc = wgrad(ctx, st, dqkv[i], INNER, INNER, b.y, D, D, M, wpart, gw[i], D, 0))) return rc;
+            if ((rc = colsum(ctx, st, dqkv[i], INNER, M, INNER, nullptr, 0, cpart, gb[i]))) return rc;
+            dgrad(st, dqkv[i], INNER, pw[i], INNER, D, M, dA, i > 0);                               // d_y (summed)
+        }
+        hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(rows_g), dim3(256), 0, st, b.x_in, L.norm_w, dA, dX, M, dX, gx);
+        if ((rc = colsum(ctx, st, gx, D, M, D, nullptr, 0, cpart, GLP(norm_w)))) return rc;
+        if ((rc = colsum(ctx, st, dA, D, M, D, nullptr, 0, cpart, GLP(norm_b)))) return rc;
+        // dX now holds d x_in of this layer
+#undef GLP
+    }
+
+    // ---- side embeddings (x0 = conv2 + Lin(lf0) + Lin(phase/pi) + Lin(vol) + spk) ----
+    if ((rc = colsum(ctx, st, dX, D, M, D, in.f0, 2, cpart, G(f0_w)))) return rc;
+    if ((rc = colsum(ctx, st, dX, D, M, D, in.phase, 3, cpart, G(phase_w)))) return rc;
+    if ((rc = colsum(ctx, st, dX, D, M, D, in.volume, 1, cpart, G(volume_w)))) return rc;
+    if ((rc = colsum(ctx, st, dX, D, M, D, nullptr, 0, cpart, G(f0_b)))) return rc;
+    DDSP_HIP(ctx, hipMemcpyAsync(G(phase_b), G(f0_b), D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    DDSP_HIP(ctx, hipMemcpyAsync(G(volume_b), G(f0_b), D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    DDSP_HIP(ctx, hipMemsetAsync(G(spk_table), 0, (size_t)w.n_spk * D * sizeof(float), st));
+    hipLaunchKernelGGL(spk_embed_bwd_kernel, dim3((unsigned)B), dim3(D), 0, st, dX, B, (int)Fr, in.spk_id, in.n_spk_id,
+                       in.mix, G(spk_table));
+    if ((rc = colsum(ctx, st, dX, D, M, D, nullptr, 0, cpart, G(prenet_conv2_b)))) return rc;
+    // ---- prenet conv2: weight gradient by taps (shifted copies of its input), input gradient as the flipped conv ----
+    for (int tap = 0; tap < 3; ++tap) {
+        hipLaunchKernelGGL(shift_rows_kernel, dim3(grid_for(M * (D / 4))), dim3(256), 0, st, bf.t2, M, (int)Fr, D, tap - 1, xs);
+        if ((rc = wgrad(ctx, st, dX, D, D, xs, D, D, M, wpart, pk, 3 * D, tap * D))) return rc;
+    }
+    hipLaunchKernelGGL(unpack_conv3_kernel, dim3(grid_for((int64_t)D * D * 3)), dim3(256), 0, st, pk, D, D, G(prenet_conv2_w));
+    hipLaunchKernelGGL(pack_conv3_transposed_kernel, dim3(grid_for((int64_t)D * D * 3)), dim3(256), 0, st, w.prenet_conv2_w, D, D, w2t);
+    {
+        gemm::Args g = gemm::make(dX, D, w2t, 3 * D, (int)M, D, 3 * D);
+        g.Fr = (int)Fr;
+        g.Cin = D;
+        gemm::EpiStore e{dA, D, nullptr, 1, 0, 0};
+        gemm::launch<true, true, gemm::A_CONV3>(st, g, 1, e);                                      // d_t2
+    }
+    // ---- GroupNorm + LeakyReLU ----
+    hipLaunchKernelGGL(groupnorm_bwd_stats_kernel, dim3(4, (unsigned)B), dim3(256), 0, st, bf.t1, bf.t2, dA, bf.gst,
+                       w.prenet_gn_w, (int)Fr, gbst);
+    hipLaunchKernelGGL(groupnorm_bwd_apply_kernel, dim3(grid_for(M * D)), dim3(256), 0, st, bf.t1, bf.t2, dA, bf.gst, gbst,
+                       w.prenet_gn_w, M, (int)Fr, dX, gx, dA);                                     // dX = d_t1, dA = d_gn
+    if ((rc = colsum(ctx, st, gx, D, M, D, nullptr, 0, cpart, G(prenet_gn_w)))) return rc;
+    if ((rc = colsum(ctx, st, dA, D, M, D, nullptr, 0, cpart, G(prenet_gn_b)))) return rc;
+    // ---- prenet conv1 (the units carry no gradient) ----
+    if ((rc = colsum(ctx, st, dX, D, M, D, nullptr, 0, cpart, G(prenet_conv1_b)))) return rc;
+    for (int tap = 0; tap < 3; ++tap) {
+        hipLaunchKernelGGL(shift_rows_kernel, dim3(grid_for(M * (w.n_unit / 4))), dim3(256), 0, st, in.units, M, (int)Fr,
+                           w.n_unit, tap - 1, xs);
+        if ((rc = wgrad(ctx, st, dX, D, D, xs, w.n_unit, w.n_unit, M, wpart, pk, 3 * w.n_unit, tap * w.n_unit))) return rc;
+    }
+    hipLaunchKernelGGL(unpack_conv3_kernel, dim3(grid_for((int64_t)D * w.n_unit * 3)), dim3(256), 0, st, pk, D, w.n_unit,
+                       G(prenet_conv1_w));
+    DDSP_LAUNCH_CHECK(ctx);
+#undef G
     return DDSP_OK;
 }

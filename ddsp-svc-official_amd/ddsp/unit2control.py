@@ -156,6 +156,44 @@ class Unit2Control(nn.Module):
         self._packed_version = None
 
     # ---- raw pointer table ---------------------------------------------------------------------
+    def _named_tensors(self):
+        """(struct field, tensor) pairs in the order of `ddsp_u2c_weights`."""
+        pre = self.unit_prenet
+        out = [("prenet_conv1_w", pre[1].weight), ("prenet_conv1_b", pre[1].bias), ("prenet_gn_w", pre[2].weight),
+               ("prenet_gn_b", pre[2].bias), ("prenet_conv2_w", pre[4].weight), ("prenet_conv2_b", pre[4].bias),
+               ("f0_w", self.f0_embed.weight), ("f0_b", self.f0_embed.bias), ("phase_w", self.phase_embed.weight),
+               ("phase_b", self.phase_embed.bias), ("volume_w", self.volume_embed.weight),
+               ("volume_b", self.volume_embed.bias), ("spk_table", self.spk_embed.weight)]
+        for i, layer in enumerate(self.dec_post[0].net):
+            a, cm = layer.attn, layer.local_mixer.net
+            vals = dict(norm_w=layer.norm.weight, norm_b=layer.norm.bias,
+                        q_w=a.to_q.weight, q_b=a.to_q.bias, k_w=a.to_k.weight, k_b=a.to_k.bias,
+                        v_w=a.to_v.weight, v_b=a.to_v.bias, proj=a.fast_attention.projection_matrix,
+                        out_w=a.to_out.weight, out_b=a.to_out.bias,
+                        cm_ln_w=cm[0].weight, cm_ln_b=cm[0].bias, cm_pw1_w=cm[2].weight, cm_pw1_b=cm[2].bias,
+                        cm_dw_w=cm[4].weight, cm_dw_b=cm[4].bias, cm_pw2_w=cm[6].weight, cm_pw2_b=cm[6].bias)
+            out += [(f"l{i}_{k}", v) for k, v in vals.items()]
+        head = self.dec_post[2]
+        out += [("final_ln_w", self.dec_post[1].weight), ("final_ln_b", self.dec_post[1].bias),
+                ("head_g", head.weight_g), ("head_v", head.weight_v), ("head_b", head.bias)]
+        return out
+
+    def backward_flat(self, units, f0, phase, volume, spk_id, spk_mix_dict, d_ctrl):
+        """Gradients of every parameter for an upstream d_ctrl (B,Fr,n_out): {parameter tensor: gradient tensor}."""
+        ctx = hipddsp.context_for(units.device)
+        w, keep = self._weights_struct()
+        g = hipddsp.U2CWeights()
+        grads = {}
+        for name, t in self._named_tensors():
+            if name.endswith("_proj"):
+                continue
+            gt = torch.empty_like(t, dtype=torch.float32, memory_format=torch.contiguous_format)
+            grads[t] = gt
+            setattr(g, name, gt.data_ptr())
+        g.n_spk, g.n_unit, g.n_out = self.n_spk, self.n_unit, self.n_out
+        ctx.unit2ctrl_bwd(w, g, units, f0, phase, volume, spk_id, spk_mix_dict, self.n_out, d_ctrl)
+        return grads
+
     def _weights_struct(self):
         w = hipddsp.U2CWeights()
         keep = []

@@ -64,11 +64,14 @@ SIGNATURES = {
     "ddsp_rss_loss": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _c.POINTER(_int), _int, _f32, _f32, _vp, _vp]),
     "ddsp_sola": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp]),
     "ddsp_volume_gate": (_int, [_vp, _vp, _vp, _vp, _f32, _i64, _i64, _int]),
+    "ddsp_adamw_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64]),
     "ddsp_gemm_f32": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _i64, _int, _vp, _vp, _i64, _int, _int, _int, _int, _int]),
     "ddsp_profile_begin": (_int, [_vp, _u64]),
     "ddsp_profile_end": (_int, [_vp, _c.POINTER(ProfEntry), _int, _c.POINTER(_int)]),
     "ddsp_unit2ctrl_fwd": (_int, [_vp, _vp, _c.POINTER(U2CWeights), _vp, _vp, _vp, _vp, _vp, _i64,
                                   _c.POINTER(_i64), _c.POINTER(_f32), _int, _i64, _i64, _vp]),
+    "ddsp_unit2ctrl_bwd": (_int, [_vp, _vp, _c.POINTER(U2CWeights), _vp, _vp, _vp, _vp, _vp, _i64,
+                                  _c.POINTER(_i64), _c.POINTER(_f32), _int, _i64, _i64, _vp, _c.POINTER(U2CWeights), _vp]),
     "ddsp_ltv_fir": (_int, [_vp, _vp, _vp, _int, _u64, _vp, _i64, _i64, _int, _int, _vp, _vp, _vp]),
 }
 
@@ -213,6 +216,30 @@ class Context:
                   n_sid, ids, ws, n_mix, B, Fr, _ptr(ctrl))
         return ctrl
 
+    def unit2ctrl_bwd(self, weights, grads, units, f0_frames, phase_frames, volume, spk_id, spk_mix_dict, n_out,
+                      d_ctrl, want_ctrl=False):
+        """Back-propagates d_ctrl (B,Fr,n_out) into the tensors `grads` points at (same struct layout as `weights`)."""
+        B, Fr, _ = units.shape
+        dev = units.device
+        units = units.contiguous().float()
+        f0 = f0_frames.reshape(B, Fr).contiguous().float()
+        ph = phase_frames.reshape(B, Fr).contiguous().float()
+        vol = volume.reshape(B, Fr).contiguous().float()
+        d_ctrl = d_ctrl.contiguous().float()
+        ctrl = torch.empty(B, Fr, n_out, device=dev, dtype=torch.float32) if want_ctrl else None
+        if spk_mix_dict is not None:
+            n_mix = len(spk_mix_dict)
+            ids = (_i64 * max(n_mix, 1))(*[int(k) for k in spk_mix_dict.keys()])
+            ws = (_f32 * max(n_mix, 1))(*[float(v) for v in spk_mix_dict.values()])
+            sid, n_sid = None, 0
+        else:
+            n_mix, ids, ws = 0, None, None
+            sid = spk_id.reshape(-1).to(device=dev, dtype=torch.int64).contiguous()
+            n_sid = sid.numel()
+        self.call("ddsp_unit2ctrl_bwd", ctypes.byref(weights), _ptr(units), _ptr(f0), _ptr(ph), _ptr(vol), _ptr(sid),
+                  n_sid, ids, ws, n_mix, B, Fr, _ptr(d_ctrl), ctypes.byref(grads), _ptr(ctrl))
+        return ctrl
+
     # -- a5-a6 ---------------------------------------------------------------------------------
     def fir_from_ctrl(self, mode, ctrl2d, col0, n_mag, rows, sr, f0_frames=None):
         """ctrl2d :: (rows, ld) contiguous; the filter's control values are columns [col0, col0+n_mag)."""
@@ -252,6 +279,11 @@ class Context:
         f0 = None if f0_frames is None else f0_frames.reshape(-1).contiguous().float()
         self.call("ddsp_fir_from_ctrl_bwd", int(mode), _ptr(ctrl2d) + 4 * col0, ctrl2d.shape[-1], int(n_mag), _ptr(f0),
                   rows, int(sr), _ptr(d_ir), _ptr(d_ctrl2d) + 4 * col0, d_ctrl2d.shape[-1])
+
+    # -- a15 optimiser -------------------------------------------------------------------------
+    def adamw_step(self, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):
+        self.call("ddsp_adamw_step", _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), float(lr),
+                  float(beta1), float(beta2), float(eps), float(weight_decay), int(step))
 
     # -- building block ------------------------------------------------------------------------
     def gemm(self, A, B, bias=None, a_k_contig=True, b_k_contig=True, tile=0, variant=0):

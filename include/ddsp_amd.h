@@ -120,6 +120,17 @@ int ddsp_unit2ctrl_fwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_weights* weig
                        const int64_t* spk_id, int64_t n_spk_id, const int64_t* mix_ids_host,
                        const float* mix_w_host, int n_mix, int64_t B, int64_t Fr, float* ctrl);
 
+/* Backward of ddsp_unit2ctrl_fwd for training (reference: autograd through Unit2Control, solver.py:113).  The call
+ * re-runs the forward keeping its activations in the scratch arena, then back-propagates d_ctrl (B,Fr,n_out) to
+ * every parameter.  `grads_host` has the layout of ddsp_u2c_weights; each pointer receives the gradient of the
+ * like-named parameter (written, not accumulated; fast_attention.projection_matrix is a buffer: `proj` is ignored).
+ * ctrl_out (B,Fr,n_out) or NULL additionally receives the forward result.  Inputs carry no gradient. */
+int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_weights* weights_host, const float* units,
+                       const float* f0_frames, const float* phase_frames, const float* volume,
+                       const int64_t* spk_id, int64_t n_spk_id, const int64_t* mix_ids_host,
+                       const float* mix_w_host, int n_mix, int64_t B, int64_t Fr, const float* d_ctrl,
+                       const ddsp_u2c_weights* grads_host, float* ctrl_out);
+
 /* ---- backward of a5-a8 (training: reference autograd through frequency_filter, solver.py:113) ------------ */
 /* Adjoints of ddsp_ltv_fir for an upstream gradient d_out (B,T): d_audio (B,T) or NULL = gradient w.r.t. the
  * input signal; d_ir (B,Fr,n) or NULL = gradient w.r.t. the filter frames (needs the forward input: audio with
@@ -173,6 +184,12 @@ int ddsp_sola(ddsp_ctx* ctx, void* stream, const float* audio, int64_t n_audio, 
  * in place (threshold = 10^(dB/20), linear); volume (B,Fr). */
 int ddsp_volume_gate(ddsp_ctx* ctx, void* stream, float* signal, const float* volume, float threshold, int64_t B,
                      int64_t Fr, int hop);
+
+/* ---- a15: optimiser step --------------------------------------------------------------------- */
+/* replaces one parameter's update of torch.optim.AdamW (train.py:41, solver.py:114): decoupled weight decay,
+ * bias-corrected moments, `step` counted from 1.  All buffers hold n fp32 values. */
+int ddsp_adamw_step(ddsp_ctx* ctx, void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step);
 
 /* ---- building block: fp32-in / fp32-accumulate MFMA GEMM ---------------------------------------- */
 /* C[m][n] = sum_k A(m,k) B(k,n) (+ bias[n]).  a_k_contig: A(m,k) = A[m*lda+k] else A[k*lda+m];

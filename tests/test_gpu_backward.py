@@ -81,3 +81,42 @@ def test_fir_from_ctrl_adjoint(ctx, dev, mode, n_mag):
     got = d_ctrl.cpu().reshape(B, Fr, W)
     assert torch.all(got[..., :8] == 7.0) and torch.all(got[..., 8 + n_mag:] == 7.0)    # only its column block is written
     assert _rel(got[..., 8:8 + n_mag], sub.grad) < (2e-4 if mode == 0 else 2e-5), _rel(got[..., 8:8 + n_mag], sub.grad)
+
+
+# ---- control network backward -------------------------------------------------------------------------
+@pytest.mark.parametrize("B,Fr,spk_mode", [(2, 12, "per_row"), (3, 40, "broadcast"), (2, 172, "mix")])
+def test_unit2ctrl_parameter_gradients(dev, lib_path, B, Fr, spk_mode):
+    import synthetic
+    from oracle import ctrlnet as OC
+    model, cfg = synthetic.build_model("CombSub", seed=31)
+    u2c = model.unit2ctrl
+    inp = synthetic.make_inputs(100 + Fr, B, Fr, with_noise=False)
+    r = _rng(Fr)
+    phase = torch.from_numpy(r.uniform(-np.pi, np.pi, (B, Fr)).astype(np.float32))
+    d_ctrl = torch.from_numpy(r.standard_normal((B, Fr, u2c.n_out)).astype(np.float32)) / (B * Fr)
+    spk = inp["spk_id"] if spk_mode == "per_row" else inp["spk_id"][:1]
+    if spk_mode == "per_row" and B > 1:
+        spk[1] = spk[0]                                  # two utterances of one speaker: gradients must add up
+    mix = {3: 0.5, 10: 0.2, 99: 0.3} if spk_mode == "mix" else None
+    # oracle gradients by autograd
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and "projection_matrix" not in k)
+          for k, v in u2c.state_dict().items()}
+    out = OC.unit2control(sd, inp["units"], inp["f0"], phase, inp["volume"], spk, mix, u2c.output_splits, return_flat=True)
+    (out * d_ctrl).sum().backward()
+    model = model.to(dev)
+    grads = model.unit2ctrl.backward_flat(inp["units"].to(dev), inp["f0"].to(dev), phase.to(dev), inp["volume"].to(dev),
+                                          spk.to(dev), mix, d_ctrl.to(dev))
+    by_name = {n: grads[p] for n, p in model.unit2ctrl.named_parameters()}
+    assert len(by_name) == len([k for k, v in sd.items() if v.requires_grad])
+    worst = []
+    for name, g in by_name.items():
+        want = sd[name].grad
+        assert want is not None and g.shape == want.shape, name
+        err = _rel(g.cpu(), want)
+        worst.append((err, name))
+        if name == "spk_embed.weight":
+            used = want.abs().sum(1) > 0
+            assert torch.all(g.cpu()[~used] == 0)
+    worst.sort(reverse=True)
+    assert worst[0][0] < 2e-3, worst[:5]
+    assert sum(e for e, _ in worst) / len(worst) < 3e-4, worst[:5]
