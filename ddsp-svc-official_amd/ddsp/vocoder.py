@@ -81,11 +81,78 @@ class _SynthBase(torch.nn.Module):
         ctx = hipddsp.context_for(f0_frames.device)
         return ctx, ctx.phase_scan(f0_frames, self._hop, self._sr, initial_phase, bool(infer), comb_mode, **want)
 
+    def _refuse_training(self):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                f"{type(self).__name__}: the backward kernels of this synthesiser are not built yet (CombSub's are); "
+                "call it under torch.no_grad() for inference")
+
     @staticmethod
     def _noise_args(noise, noise_seed):
         if noise is not None:
             return noise.contiguous().float(), EXC_UNIT_NOISE, 0
         return None, EXC_GENERATE, (_seed_from_torch() if noise_seed is None else int(noise_seed))
+
+
+class _CombSubTrainFn(torch.autograd.Function):
+    """Autograd node of one CombSub forward: the whole forward and backward are libddsp_amd calls; torch only
+    routes the parameter gradients (reference: autograd through `CombSub.forward`, solver.py:111-113)."""
+
+    @staticmethod
+    def forward(fctx, model, units, f0_frames, volume, spk_id, spk_mix_dict, initial_phase, infer, noise, noise_seed,
+                *params):
+        ctx, ps = model._front(f0_frames, initial_phase, infer, COMB_SINC)
+        ctrl = model.unit2ctrl.forward_flat(units, f0_frames, ps["phase_frames"], volume, spk_id, spk_mix_dict)
+        B, Fr = ctrl.shape[0], ctrl.shape[1]
+        rows, sr, hop = B * Fr, model._sr, model._hop
+        na, nh, nn_ = model.n_mags
+        c2 = ctrl.reshape(rows, -1)
+        ir_ap = ctx.fir_from_ctrl(FIR_ALLPASS, c2, 0, na, rows, sr)
+        h1, _ = ctx.ltv_fir(ps["comb"], ir_ap, B, Fr, hop)
+        ir_h = ctx.fir_from_ctrl(FIR_DYNAMIC, c2, na, nh, rows, sr, f0_frames)
+        harmonic, _ = ctx.ltv_fir(h1, ir_h, B, Fr, hop)
+        ir_n = ctx.fir_from_ctrl(FIR_STATIC, c2, na + nh, nn_, rows, sr)
+        nz, exc, seed = model._noise_args(noise, noise_seed)
+        noise_out, signal = ctx.ltv_fir(nz, ir_n, B, Fr, hop, excitation=exc, noise_seed=seed, add_in=harmonic)
+        fctx.model, fctx.dsp = model, ctx
+        fctx.args = (units, f0_frames, volume, spk_id, spk_mix_dict, nz, exc, seed, B, Fr)
+        fctx.saved = (ctrl, ps["comb"], ps["phase_frames"], h1, ir_ap, ir_h, ir_n)
+        fctx.mark_non_differentiable(ps["phase_frames"])
+        return signal, ps["phase_frames"], harmonic, noise_out
+
+    @staticmethod
+    def backward(fctx, d_signal, d_phase, d_harm, d_noise):
+        model, ctx = fctx.model, fctx.dsp
+        units, f0_frames, volume, spk_id, spk_mix_dict, nz, exc, seed, B, Fr = fctx.args
+        ctrl, comb, phase_frames, h1, ir_ap, ir_h, ir_n = fctx.saved
+        rows, sr, hop = B * Fr, model._sr, model._hop
+        na, nh, nn_ = model.n_mags
+        zeros = None
+
+        def total(a, b):
+            nonlocal zeros
+            if a is None and b is None:
+                if zeros is None:
+                    zeros = torch.zeros(B, Fr * hop, device=ctrl.device)
+                return zeros
+            if a is None:
+                return b.contiguous()
+            return a.contiguous() if b is None else (a + b)
+
+        d_h = total(d_signal, d_harm)
+        d_n = total(d_signal, d_noise)
+        c2 = ctrl.reshape(rows, -1)
+        d_ctrl = torch.empty_like(c2)
+        _, d_ir = ctx.ltv_fir_bwd(nz, ir_n, d_n, B, Fr, hop, excitation=exc, noise_seed=seed, want_d_audio=False)
+        ctx.fir_from_ctrl_bwd(FIR_STATIC, c2, na + nh, nn_, rows, sr, d_ir, d_ctrl)
+        d_h1, d_ir = ctx.ltv_fir_bwd(h1, ir_h, d_h, B, Fr, hop)
+        ctx.fir_from_ctrl_bwd(FIR_DYNAMIC, c2, na, nh, rows, sr, d_ir, d_ctrl, f0_frames)
+        _, d_ir = ctx.ltv_fir_bwd(comb, ir_ap, d_h1, B, Fr, hop, want_d_audio=False)
+        ctx.fir_from_ctrl_bwd(FIR_ALLPASS, c2, 0, na, rows, sr, d_ir, d_ctrl)
+        grads = model.unit2ctrl.backward_flat(units, f0_frames, phase_frames, volume, spk_id, spk_mix_dict,
+                                              d_ctrl.reshape(B, Fr, -1))
+        fctx.saved = None
+        return (None,) * 10 + tuple(grads.get(p) for p in model.unit2ctrl.parameters())
 
 
 class CombSub(_SynthBase):
@@ -119,6 +186,11 @@ class CombSub(_SynthBase):
                 infer=True, noise=None, noise_seed=None, **kwargs):
         """units (B,Fr,n_unit), f0 (B,Fr,1) Hz, volume (B,Fr), spk_id (B,1)|(1,1) int64 1-based ->
         (signal (B,T), phase_frames (B,Fr,1), (harmonic (B,T), noise (B,T)))."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.unit2ctrl.parameters()):
+            signal, pf, harmonic, noise_out = _CombSubTrainFn.apply(
+                self, units_frames, f0_frames, volume_frames, spk_id, spk_mix_dict, initial_phase, infer, noise,
+                noise_seed, *self.unit2ctrl.parameters())
+            return signal, pf.unsqueeze(-1), (harmonic, noise_out)
         ctx, ps = self._front(f0_frames, initial_phase, infer, COMB_SINC)
         ctrl = self.unit2ctrl.forward_flat(units_frames, f0_frames, ps["phase_frames"], volume_frames, spk_id,
                                            spk_mix_dict)
@@ -155,6 +227,7 @@ class Sins(_SynthBase):
         """Same contract as CombSub.forward except that the returned phase is sample-rate (B,T,1)
         (reference `ddsp/vocoder.py:423`).  `max_upsample_dim` is accepted and ignored: the bank kernel never
         materialises the (B,T,chunk) tensors the reference chunks to bound."""
+        self._refuse_training()
         ctx, ps = self._front(f0_frames, initial_phase, infer, COMB_NONE, want_phase=True)
         ctrl = self.unit2ctrl.forward_flat(units_frames, f0_frames, ps["phase_frames"], volume_frames, spk_id,
                                            spk_mix_dict)
@@ -182,6 +255,7 @@ class CombSubFast(_SynthBase):
                 infer=True, noise=None, noise_seed=None, **kwargs):
         """Returns (signal, phase_frames (B,Fr,1), (signal, signal)) - the same tensor three times, like the
         reference (`ddsp/vocoder.py:492`)."""
+        self._refuse_training()
         ctx, ps = self._front(f0_frames, initial_phase, infer, COMB_SINC_GATED)
         ctrl = self.unit2ctrl.forward_flat(units_frames, f0_frames, ps["phase_frames"], volume_frames, spk_id,
                                            spk_mix_dict)
