@@ -59,6 +59,91 @@ __global__ void __launch_bounds__(256) sins_bank_kernel(const float* __restrict_
     }
 }
 
+
+// Backward w.r.t. the amplitude controls.  out[t] = sum_k lerp_t(A_k) sin(k phase_t) and A = exp(ctrl)/128 * aa, so
+//   d ctrl[m][k] = A[m][k] * ( sum_{t in seg m} (1 - j/hop) sin(k phase_t) d_t  +  sum_{t in seg m-1} (j/hop) sin(k phase_t) d_t )
+// (frame Fr-1 also receives the j/hop share of its own segment: the upsampler repeats the last frame).
+// One workgroup per (utterance, segment): every lane walks the harmonics of its samples with the same rotation
+// recurrence as the forward kernel; per harmonic the two window-weighted sums are reduced across the workgroup
+// (DPP wave reduction + LDS), and written as partials [seg][2][H] that a second pass combines.
+__global__ void __launch_bounds__(256) sins_bank_bwd_partial_kernel(const float* __restrict__ phase,
+                                                                    const float* __restrict__ dout, int H, int Fr, int hop,
+                                                                    float* __restrict__ partial) {
+    extern __shared__ float red[];  // [4 waves][2][H]
+    const int m = blockIdx.x, b = blockIdx.y;
+    const int64_t row = (int64_t)b * Fr + m;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv_hop = 1.0f / (float)hop;
+    // this lane's samples (hop / 256 of them, at most 4)
+    float ph[4], g0[4], g1[4], s1[4], c1[4];
+    const int per = (hop + 255) / 256;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = threadIdx.x + 256 * i;
+        ph[i] = 0.f;
+        g0[i] = 0.f;
+        g1[i] = 0.f;
+        if (i < per && j < hop) {
+            const int64_t t = row * hop + j;
+            ph[i] = phase[t];
+            const float d = dout[t], w1 = (float)j * inv_hop;
+            g0[i] = (1.0f - w1) * d;
+            g1[i] = w1 * d;
+        }
+        sincosf(ph[i], &s1[i], &c1[i]);
+    }
+    for (int k0 = 0; k0 < H; k0 += RESEED) {
+        float zs[4], zc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sincosf(__fmul_rn(ph[i], (float)(k0 + 1)), &zs[i], &zc[i]);
+        const int kend = (k0 + RESEED < H) ? k0 + RESEED : H;
+        for (int k = k0; k < kend; ++k) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a0 = fmaf(g0[i], zs[i], a0);
+                a1 = fmaf(g1[i], zs[i], a1);
+                const float nc = fmaf(zc[i], c1[i], -zs[i] * s1[i]);
+                const float ns = fmaf(zs[i], c1[i], zc[i] * s1[i]);
+                zc[i] = nc;
+                zs[i] = ns;
+            }
+            a0 = wave_sum(a0);
+            a1 = wave_sum(a1);
+            if (lane == 0) {
+                red[(wave * 2 + 0) * H + k] = a0;
+                red[(wave * 2 + 1) * H + k] = a1;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * H; i += 256) {
+        const int which = i / H, k = i % H;
+        partial[(row * 2 + which) * H + k] = (red[(0 * 2 + which) * H + k] + red[(1 * 2 + which) * H + k]) +
+                                             (red[(2 * 2 + which) * H + k] + red[(3 * 2 + which) * H + k]);
+    }
+}
+
+__global__ void __launch_bounds__(256) sins_bank_bwd_combine_kernel(const float* __restrict__ ctrl, int64_t ld, int H,
+                                                                    const float* __restrict__ f0_frames,
+                                                                    const float* __restrict__ partial, int64_t rows,
+                                                                    int Fr, float fmax, float* __restrict__ d_ctrl,
+                                                                    int64_t ldo) {
+    const int64_t total = rows * H;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / H;
+        const int k = (int)(i % H);
+        const int m = (int)(r % Fr);
+        float g = partial[(r * 2 + 0) * H + k];                     // (1 - j/hop) share of its own segment
+        if (m > 0) g += partial[((r - 1) * 2 + 1) * H + k];         // j/hop share of the previous segment
+        if (m == Fr - 1) g += partial[(r * 2 + 1) * H + k];         // last frame is its own successor
+        const float a = __fdiv_rn(expf(ctrl[r * ld + k]), 128.0f);
+        const float pk = __fmul_rn(f0_frames[r], (float)(k + 1));
+        const float aa = __fadd_rn(pk < fmax ? 1.0f : 0.0f, 1e-7f);
+        d_ctrl[r * ldo + k] = g * __fmul_rn(a, aa);
+    }
+}
+
 }  // namespace
 
 extern "C" int ddsp_sins_bank(ddsp_ctx* ctx, void* stream, const float* ctrl, int64_t ctrl_ld, int n_harmonics,
@@ -75,6 +160,36 @@ extern "C" int ddsp_sins_bank(ddsp_ctx* ctx, void* stream, const float* ctrl, in
                        ctrl, ctrl_ld, n_harmonics, f0_frames, phase, (int)Fr, hop, (float)sr / 2.0f, out);
     ddsp_prof_end(ctx, st, 7.0 * B * Fr * hop * (double)n_harmonics,
                   4.0 * B * Fr * ((double)n_harmonics + 1 + 2.0 * hop));
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}
+
+extern "C" int ddsp_sins_bank_bwd(ddsp_ctx* ctx, void* stream, const float* ctrl, int64_t ctrl_ld, int n_harmonics,
+                                  const float* f0_frames, const float* phase, const float* d_out, int64_t B, int64_t Fr,
+                                  int hop, int sr, float* d_ctrl, int64_t d_ctrl_ld) {
+    DDSP_REQUIRE(ctx, ctx && ctrl && f0_frames && phase && d_out && d_ctrl, "ddsp_sins_bank_bwd: null argument");
+    DDSP_REQUIRE(ctx, n_harmonics >= 1 && n_harmonics <= 4096 && ctrl_ld >= n_harmonics && d_ctrl_ld >= n_harmonics,
+                 "ddsp_sins_bank_bwd: bad harmonics");
+    DDSP_REQUIRE(ctx, B >= 0 && B <= 65535 && Fr >= 1 && hop >= 1 && hop <= 1024 && (hop & (hop - 1)) == 0,
+                 "ddsp_sins_bank_bwd: bad shape (hop must be a power of two <= 1024)");
+    if (B == 0) return DDSP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t rows = B * Fr;
+    const size_t pf = (size_t)rows * 2 * n_harmonics;
+    int rc = ddsp_scratch_reserve_bytes(ctx, pf * sizeof(float) + 4096);
+    if (rc) return rc;
+    ddsp_scratch_reset(ctx);
+    float* partial = nullptr;
+    if ((rc = ddsp_scratch_get(ctx, pf * sizeof(float), (void**)&partial))) return rc;
+    ddsp_prof_begin(ctx, st, PF_SINS_BANK);
+    hipLaunchKernelGGL(sins_bank_bwd_partial_kernel, dim3((unsigned)Fr, (unsigned)B), dim3(256),
+                       8 * n_harmonics * sizeof(float), st, phase, d_out, n_harmonics, (int)Fr, hop, partial);
+    int64_t blocks = ceil_div64(rows * n_harmonics, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sins_bank_bwd_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ctrl, ctrl_ld, n_harmonics,
+                       f0_frames, partial, rows, (int)Fr, (float)sr / 2.0f, d_ctrl, d_ctrl_ld);
+    ddsp_prof_end(ctx, st, 10.0 * B * Fr * hop * (double)n_harmonics, 4.0 * B * Fr * (3.0 * n_harmonics + 2.0 * hop));
     DDSP_LAUNCH_CHECK(ctx);
     return DDSP_OK;
 }

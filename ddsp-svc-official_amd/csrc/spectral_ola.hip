@@ -152,6 +152,90 @@ __global__ void __launch_bounds__(256) overlap_add_kernel(const float* __restric
     }
 }
 
+
+// Backward w.r.t. the three control blocks.  With g = win * d_out (the frame's slice of the upstream gradient) and
+// its forward DFT G, the gradient on the one-sided spectrum is dY_f = c_f/N * G_f (c = 1 at DC/Nyquist, else 2;
+// imaginary parts of those two bins carry none), and with Y = C*H + W*g_n, H = exp(hm + j*pi*hp), g_n = exp(nm)/128:
+//   dH = conj(C) dY,  d_hm = Re(conj(H) dH),  d_hp = pi * Im(conj(H) dH),  d_nm = g_n * Re(conj(W) dY).
+// One workgroup per filter frame m < Fr; frame Fr shares filter Fr-1 and is folded into that workgroup.
+__global__ void __launch_bounds__(256) spectral_frame_bwd_kernel(const float* __restrict__ ctrl, int64_t ld,
+                                                                 const float* __restrict__ comb,
+                                                                 const float* __restrict__ noise, int excitation,
+                                                                 uint64_t seed, const float* __restrict__ dout,
+                                                                 const float* __restrict__ tab, int Fr,
+                                                                 float* __restrict__ d_ctrl, int64_t ldo) {
+    __shared__ c32 A[N];
+    __shared__ c32 Bf[N];
+    __shared__ c32 Gs[N];
+    __shared__ c32 tw[N];
+    __shared__ float win[N];
+    const int m0 = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int64_t T = (int64_t)Fr * HOP;
+    for (int i = tid; i < N; i += 256) {
+        tw[i] = {tab[2 * i], tab[2 * i + 1]};
+        win[i] = tab[2 * N + i];
+    }
+    const float* cr = ctrl + ((int64_t)b * Fr + m0) * ld;
+    float* dr = d_ctrl + ((int64_t)b * Fr + m0) * ldo;
+    const float pi_f = 3.14159274101257324f;
+    float acc[3][3];  // [bin slot of this thread][hm, hp, nm]; bins f = tid, tid+256, 512 (tid == 0)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[i][0] = acc[i][1] = acc[i][2] = 0.f;
+    const int n_pass = (m0 == Fr - 1) ? 2 : 1;
+    for (int pass = 0; pass < n_pass; ++pass) {
+        const int m = m0 + pass;
+        __syncthreads();
+        for (int i = tid; i < N; i += 256) {
+            const int64_t t = (int64_t)HOP * (m - 1) + i;
+            float c = 0.f, z = 0.f, g = 0.f;
+            if (t >= 0 && t < T) {
+                c = comb[(int64_t)b * T + t];
+                if (excitation == DDSP_EXC_GENERATE)
+                    z = noise_u(seed, (uint64_t)b * T + t);
+                else
+                    z = __fadd_rn(__fmul_rn(noise[(int64_t)b * T + t], 2.0f), -1.0f);
+                g = dout[(int64_t)b * T + t];
+            }
+            A[i] = {c * win[i], z * win[i]};
+            Gs[i] = {g * win[i], 0.f};
+        }
+        __syncthreads();
+        fft1024<-1>(A, Bf, tw, tid);      // packed spectra of comb / noise frames in Bf
+        // the second transform needs two scratch buffers: A is free again, result lands in A (odd number of passes
+        // starting from Gs)
+        fft1024<-1>(Gs, A, tw, tid);      // G in A
+#pragma unroll
+        for (int slot = 0; slot < 3; ++slot) {
+            const int f = slot < 2 ? tid + 256 * slot : N / 2;
+            if (slot == 2 && tid != 0) continue;
+            const c32 zf = Bf[f], zn = Bf[(N - f) & (N - 1)];
+            const c32 C = {0.5f * (zf.x + zn.x), 0.5f * (zf.y - zn.y)};
+            const c32 W = {0.5f * (zf.y + zn.y), -0.5f * (zf.x - zn.x)};
+            const float cf = (f == 0 || f == N / 2) ? 1.0f : 2.0f;
+            c32 dY = {cf * (1.0f / N) * A[f].x, cf * (1.0f / N) * A[f].y};
+            if (f == 0 || f == N / 2) dY.y = 0.f;
+            const float mag = expf(cr[f]);
+            float sn, cs;
+            sincosf(__fmul_rn(pi_f, cr[NB + f]), &sn, &cs);
+            const c32 Hh = {mag * cs, mag * sn};
+            const c32 dH = {C.x * dY.x + C.y * dY.y, C.x * dY.y - C.y * dY.x};          // conj(C) * dY
+            const c32 hd = {Hh.x * dH.x + Hh.y * dH.y, Hh.x * dH.y - Hh.y * dH.x};      // conj(H) * dH
+            const float gn = __fdiv_rn(expf(cr[2 * NB + f]), 128.0f);
+            acc[slot][0] += hd.x;
+            acc[slot][1] += pi_f * hd.y;
+            acc[slot][2] += gn * (W.x * dY.x + W.y * dY.y);                              // Re(conj(W) dY)
+        }
+    }
+#pragma unroll
+    for (int slot = 0; slot < 3; ++slot) {
+        const int f = slot < 2 ? tid + 256 * slot : N / 2;
+        if (slot == 2 && tid != 0) continue;
+        dr[f] = acc[slot][0];
+        dr[NB + f] = acc[slot][1];
+        dr[2 * NB + f] = acc[slot][2];
+    }
+}
+
 }  // namespace
 
 extern "C" int ddsp_spectral_ola(ddsp_ctx* ctx, void* stream, const float* ctrl, int64_t ctrl_ld, const float* comb,
@@ -182,6 +266,31 @@ extern "C" int ddsp_spectral_ola(ddsp_ctx* ctx, void* stream, const float* ctrl,
     hipLaunchKernelGGL(overlap_add_kernel, dim3((unsigned)blocks), dim3(256), 0, st, frames, (int)Fr, total, out);
     ddsp_prof_end(ctx, st, 2.0 * B * (Fr + 1) * 5.0 * N * 10.0 * 2.0,
                   4.0 * B * Fr * (3.0 * NB + 2.0 * HOP + 1.0 * HOP) + 2.0 * fbytes);
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}
+
+extern "C" int ddsp_spectral_ola_bwd(ddsp_ctx* ctx, void* stream, const float* ctrl, int64_t ctrl_ld, const float* comb,
+                                     const float* noise, int excitation, uint64_t noise_seed, const float* d_out,
+                                     int64_t B, int64_t Fr, int hop, float* d_ctrl, int64_t d_ctrl_ld) {
+    DDSP_REQUIRE(ctx, ctx && ctrl && comb && d_out && d_ctrl, "ddsp_spectral_ola_bwd: null argument");
+    DDSP_REQUIRE(ctx, hop == HOP, "ddsp_spectral_ola_bwd: only hop == 512 is built");
+    DDSP_REQUIRE(ctx, ctrl_ld >= 3 * NB && d_ctrl_ld >= 3 * NB && B >= 0 && B <= 65535 && Fr >= 1, "ddsp_spectral_ola_bwd: bad shape");
+    DDSP_REQUIRE(ctx, excitation == DDSP_EXC_GENERATE || (excitation == DDSP_EXC_UNIT_NOISE && noise),
+                 "ddsp_spectral_ola_bwd: excitation must be UNIT_NOISE (with a noise buffer) or GENERATE");
+    if (B == 0) return DDSP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ddsp_scratch_reserve_bytes(ctx, 3 * N * sizeof(float) + 8192);
+    if (rc) return rc;
+    ddsp_scratch_reset(ctx);
+    float* tab = nullptr;
+    if ((rc = ddsp_scratch_get(ctx, 3 * N * sizeof(float), (void**)&tab))) return rc;
+    ddsp_prof_begin(ctx, st, PF_SPECTRAL_OLA);
+    hipLaunchKernelGGL(twiddle_kernel, dim3(N / 256), dim3(256), 0, st, tab);
+    hipLaunchKernelGGL(spectral_frame_bwd_kernel, dim3((unsigned)Fr, (unsigned)B), dim3(256), 0, st, ctrl, ctrl_ld, comb,
+                       noise, excitation, noise_seed, d_out, tab, (int)Fr, d_ctrl, d_ctrl_ld);
+    ddsp_prof_end(ctx, st, 2.0 * B * (Fr + 1) * 5.0 * N * 10.0 * 2.0, 4.0 * B * Fr * (6.0 * NB + 3.0 * HOP));
     DDSP_LAUNCH_CHECK(ctx);
     return DDSP_OK;
 }

@@ -81,11 +81,9 @@ class _SynthBase(torch.nn.Module):
         ctx = hipddsp.context_for(f0_frames.device)
         return ctx, ctx.phase_scan(f0_frames, self._hop, self._sr, initial_phase, bool(infer), comb_mode, **want)
 
-    def _refuse_training(self):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                f"{type(self).__name__}: the backward kernels of this synthesiser are not built yet (CombSub's are); "
-                "call it under torch.no_grad() for inference")
+    def _training_graph(self):
+        """True when the call must be recorded for autograd (grad mode on and some parameter wants a gradient)."""
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.unit2ctrl.parameters())
 
     @staticmethod
     def _noise_args(noise, noise_seed):
@@ -94,65 +92,46 @@ class _SynthBase(torch.nn.Module):
         return None, EXC_GENERATE, (_seed_from_torch() if noise_seed is None else int(noise_seed))
 
 
-class _CombSubTrainFn(torch.autograd.Function):
-    """Autograd node of one CombSub forward: the whole forward and backward are libddsp_amd calls; torch only
-    routes the parameter gradients (reference: autograd through `CombSub.forward`, solver.py:111-113)."""
+class _SynthTrainFn(torch.autograd.Function):
+    """Autograd node of one synthesiser forward: forward and backward are libddsp_amd calls end to end; torch only
+    routes the parameter gradients (reference: autograd through `*.forward`, solver.py:111-113).  The model supplies
+    `_train_forward(ctx, ctrl, ps, f0_frames, noise_args) -> (outputs, saved)` and
+    `_train_backward(ctx, saved, f0_frames, noise_args, grads) -> d_ctrl (rows, sum)`."""
 
     @staticmethod
     def forward(fctx, model, units, f0_frames, volume, spk_id, spk_mix_dict, initial_phase, infer, noise, noise_seed,
                 *params):
-        ctx, ps = model._front(f0_frames, initial_phase, infer, COMB_SINC)
+        ctx, ps = model._front(f0_frames, initial_phase, infer, model._comb_mode, **model._front_wants)
         ctrl = model.unit2ctrl.forward_flat(units, f0_frames, ps["phase_frames"], volume, spk_id, spk_mix_dict)
-        B, Fr = ctrl.shape[0], ctrl.shape[1]
-        rows, sr, hop = B * Fr, model._sr, model._hop
-        na, nh, nn_ = model.n_mags
-        c2 = ctrl.reshape(rows, -1)
-        ir_ap = ctx.fir_from_ctrl(FIR_ALLPASS, c2, 0, na, rows, sr)
-        h1, _ = ctx.ltv_fir(ps["comb"], ir_ap, B, Fr, hop)
-        ir_h = ctx.fir_from_ctrl(FIR_DYNAMIC, c2, na, nh, rows, sr, f0_frames)
-        harmonic, _ = ctx.ltv_fir(h1, ir_h, B, Fr, hop)
-        ir_n = ctx.fir_from_ctrl(FIR_STATIC, c2, na + nh, nn_, rows, sr)
-        nz, exc, seed = model._noise_args(noise, noise_seed)
-        noise_out, signal = ctx.ltv_fir(nz, ir_n, B, Fr, hop, excitation=exc, noise_seed=seed, add_in=harmonic)
+        nargs = model._noise_args(noise, noise_seed)
+        outs, saved = model._train_forward(ctx, ctrl, ps, f0_frames, nargs)
         fctx.model, fctx.dsp = model, ctx
-        fctx.args = (units, f0_frames, volume, spk_id, spk_mix_dict, nz, exc, seed, B, Fr)
-        fctx.saved = (ctrl, ps["comb"], ps["phase_frames"], h1, ir_ap, ir_h, ir_n)
-        fctx.mark_non_differentiable(ps["phase_frames"])
-        return signal, ps["phase_frames"], harmonic, noise_out
+        fctx.args = (units, f0_frames, volume, spk_id, spk_mix_dict, nargs, ps["phase_frames"])
+        fctx.saved = (ctrl, saved)
+        phase_out = ps["phase"] if model._front_wants.get("want_phase") else ps["phase_frames"]
+        fctx.mark_non_differentiable(phase_out)
+        return (phase_out,) + tuple(outs)
 
     @staticmethod
-    def backward(fctx, d_signal, d_phase, d_harm, d_noise):
+    def backward(fctx, d_phase, *d_outs):
         model, ctx = fctx.model, fctx.dsp
-        units, f0_frames, volume, spk_id, spk_mix_dict, nz, exc, seed, B, Fr = fctx.args
-        ctrl, comb, phase_frames, h1, ir_ap, ir_h, ir_n = fctx.saved
-        rows, sr, hop = B * Fr, model._sr, model._hop
-        na, nh, nn_ = model.n_mags
-        zeros = None
-
-        def total(a, b):
-            nonlocal zeros
-            if a is None and b is None:
-                if zeros is None:
-                    zeros = torch.zeros(B, Fr * hop, device=ctrl.device)
-                return zeros
-            if a is None:
-                return b.contiguous()
-            return a.contiguous() if b is None else (a + b)
-
-        d_h = total(d_signal, d_harm)
-        d_n = total(d_signal, d_noise)
-        c2 = ctrl.reshape(rows, -1)
-        d_ctrl = torch.empty_like(c2)
-        _, d_ir = ctx.ltv_fir_bwd(nz, ir_n, d_n, B, Fr, hop, excitation=exc, noise_seed=seed, want_d_audio=False)
-        ctx.fir_from_ctrl_bwd(FIR_STATIC, c2, na + nh, nn_, rows, sr, d_ir, d_ctrl)
-        d_h1, d_ir = ctx.ltv_fir_bwd(h1, ir_h, d_h, B, Fr, hop)
-        ctx.fir_from_ctrl_bwd(FIR_DYNAMIC, c2, na, nh, rows, sr, d_ir, d_ctrl, f0_frames)
-        _, d_ir = ctx.ltv_fir_bwd(comb, ir_ap, d_h1, B, Fr, hop, want_d_audio=False)
-        ctx.fir_from_ctrl_bwd(FIR_ALLPASS, c2, 0, na, rows, sr, d_ir, d_ctrl)
+        units, f0_frames, volume, spk_id, spk_mix_dict, nargs, phase_frames = fctx.args
+        ctrl, saved = fctx.saved
+        B, Fr = ctrl.shape[0], ctrl.shape[1]
+        d_ctrl = model._train_backward(ctx, ctrl, saved, f0_frames, nargs, d_outs)
         grads = model.unit2ctrl.backward_flat(units, f0_frames, phase_frames, volume, spk_id, spk_mix_dict,
                                               d_ctrl.reshape(B, Fr, -1))
         fctx.saved = None
         return (None,) * 10 + tuple(grads.get(p) for p in model.unit2ctrl.parameters())
+
+
+def _sum_grads(ref, *gs):
+    """Sum of the upstream gradients that exist (zeros when none does)."""
+    acc = None
+    for g in gs:
+        if g is not None:
+            acc = g.contiguous() if acc is None else acc + g
+    return torch.zeros_like(ref) if acc is None else acc
 
 
 class CombSub(_SynthBase):
@@ -166,6 +145,42 @@ class CombSub(_SynthBase):
         self.unit2ctrl = Unit2Control(n_unit, n_spk, {"group_delay": n_mag_allpass,
                                                       "harmonic_magnitude": n_mag_harmonic,
                                                       "noise_magnitude": n_mag_noise}, c)
+
+    _comb_mode = COMB_SINC
+    _front_wants = {}
+
+    def _train_forward(self, ctx, ctrl, ps, f0_frames, nargs):
+        B, Fr = ctrl.shape[0], ctrl.shape[1]
+        rows, sr, hop = B * Fr, self._sr, self._hop
+        na, nh, nn_ = self.n_mags
+        c2 = ctrl.reshape(rows, -1)
+        ir_ap = ctx.fir_from_ctrl(FIR_ALLPASS, c2, 0, na, rows, sr)
+        h1, _ = ctx.ltv_fir(ps["comb"], ir_ap, B, Fr, hop)
+        ir_h = ctx.fir_from_ctrl(FIR_DYNAMIC, c2, na, nh, rows, sr, f0_frames)
+        harmonic, _ = ctx.ltv_fir(h1, ir_h, B, Fr, hop)
+        ir_n = ctx.fir_from_ctrl(FIR_STATIC, c2, na + nh, nn_, rows, sr)
+        nz, exc, seed = nargs
+        noise_out, signal = ctx.ltv_fir(nz, ir_n, B, Fr, hop, excitation=exc, noise_seed=seed, add_in=harmonic)
+        return (signal, harmonic, noise_out), (ps["comb"], h1, ir_ap, ir_h, ir_n)
+
+    def _train_backward(self, ctx, ctrl, saved, f0_frames, nargs, d_outs):
+        comb, h1, ir_ap, ir_h, ir_n = saved
+        d_signal, d_harm, d_noise = d_outs
+        B, Fr = ctrl.shape[0], ctrl.shape[1]
+        rows, sr, hop = B * Fr, self._sr, self._hop
+        na, nh, nn_ = self.n_mags
+        nz, exc, seed = nargs
+        d_h = _sum_grads(comb, d_signal, d_harm)
+        d_n = _sum_grads(comb, d_signal, d_noise)
+        c2 = ctrl.reshape(rows, -1)
+        d_ctrl = torch.empty_like(c2)
+        _, d_ir = ctx.ltv_fir_bwd(nz, ir_n, d_n, B, Fr, hop, excitation=exc, noise_seed=seed, want_d_audio=False)
+        ctx.fir_from_ctrl_bwd(FIR_STATIC, c2, na + nh, nn_, rows, sr, d_ir, d_ctrl)
+        d_h1, d_ir = ctx.ltv_fir_bwd(h1, ir_h, d_h, B, Fr, hop)
+        ctx.fir_from_ctrl_bwd(FIR_DYNAMIC, c2, na, nh, rows, sr, d_ir, d_ctrl, f0_frames)
+        _, d_ir = ctx.ltv_fir_bwd(comb, ir_ap, d_h1, B, Fr, hop, want_d_audio=False)
+        ctx.fir_from_ctrl_bwd(FIR_ALLPASS, c2, 0, na, rows, sr, d_ir, d_ctrl)
+        return d_ctrl
 
     def synth_from_ctrl(self, ctx, ctrl, f0_frames, comb, noise=None, noise_seed=None):
         """DSP stage: fused control matrix (B,Fr,sum) + combtooth -> (signal, harmonic, noise)."""
@@ -186,8 +201,8 @@ class CombSub(_SynthBase):
                 infer=True, noise=None, noise_seed=None, **kwargs):
         """units (B,Fr,n_unit), f0 (B,Fr,1) Hz, volume (B,Fr), spk_id (B,1)|(1,1) int64 1-based ->
         (signal (B,T), phase_frames (B,Fr,1), (harmonic (B,T), noise (B,T)))."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.unit2ctrl.parameters()):
-            signal, pf, harmonic, noise_out = _CombSubTrainFn.apply(
+        if self._training_graph():
+            pf, signal, harmonic, noise_out = _SynthTrainFn.apply(
                 self, units_frames, f0_frames, volume_frames, spk_id, spk_mix_dict, initial_phase, infer, noise,
                 noise_seed, *self.unit2ctrl.parameters())
             return signal, pf.unsqueeze(-1), (harmonic, noise_out)
@@ -209,6 +224,40 @@ class Sins(_SynthBase):
         self.unit2ctrl = Unit2Control(n_unit, n_spk, {"amplitudes": n_harmonics, "group_delay": n_mag_allpass,
                                                       "noise_magnitude": n_mag_noise}, c)
 
+    _comb_mode = COMB_NONE
+    _front_wants = {"want_phase": True}
+
+    def _train_forward(self, ctx, ctrl, ps, f0_frames, nargs):
+        B, Fr = ctrl.shape[0], ctrl.shape[1]
+        rows, sr, hop = B * Fr, self._sr, self._hop
+        nhm, na, nn_ = self.n_mags
+        c2 = ctrl.reshape(rows, -1)
+        sinusoids = ctx.sins_bank(c2, 0, nhm, f0_frames, ps["phase"], B, Fr, hop, sr)
+        ir_ap = ctx.fir_from_ctrl(FIR_ALLPASS, c2, nhm, na, rows, sr)
+        harmonic, _ = ctx.ltv_fir(sinusoids, ir_ap, B, Fr, hop)
+        ir_n = ctx.fir_from_ctrl(FIR_STATIC, c2, nhm + na, nn_, rows, sr)
+        nz, exc, seed = nargs
+        noise_out, signal = ctx.ltv_fir(nz, ir_n, B, Fr, hop, excitation=exc, noise_seed=seed, add_in=harmonic)
+        return (signal, harmonic, noise_out), (ps["phase"], sinusoids, ir_ap, ir_n)
+
+    def _train_backward(self, ctx, ctrl, saved, f0_frames, nargs, d_outs):
+        phase, sinusoids, ir_ap, ir_n = saved
+        d_signal, d_harm, d_noise = d_outs
+        B, Fr = ctrl.shape[0], ctrl.shape[1]
+        rows, sr, hop = B * Fr, self._sr, self._hop
+        nhm, na, nn_ = self.n_mags
+        nz, exc, seed = nargs
+        d_h = _sum_grads(sinusoids, d_signal, d_harm)
+        d_n = _sum_grads(sinusoids, d_signal, d_noise)
+        c2 = ctrl.reshape(rows, -1)
+        d_ctrl = torch.empty_like(c2)
+        _, d_ir = ctx.ltv_fir_bwd(nz, ir_n, d_n, B, Fr, hop, excitation=exc, noise_seed=seed, want_d_audio=False)
+        ctx.fir_from_ctrl_bwd(FIR_STATIC, c2, nhm + na, nn_, rows, sr, d_ir, d_ctrl)
+        d_sin, d_ir = ctx.ltv_fir_bwd(sinusoids, ir_ap, d_h, B, Fr, hop)
+        ctx.fir_from_ctrl_bwd(FIR_ALLPASS, c2, nhm, na, rows, sr, d_ir, d_ctrl)
+        ctx.sins_bank_bwd(c2, 0, nhm, f0_frames, phase, d_sin, B, Fr, hop, sr, d_ctrl)
+        return d_ctrl
+
     def synth_from_ctrl(self, ctx, ctrl, f0_frames, phase, noise=None, noise_seed=None):
         B, Fr = ctrl.shape[0], ctrl.shape[1]
         rows, sr, hop = B * Fr, self._sr, self._hop
@@ -227,7 +276,11 @@ class Sins(_SynthBase):
         """Same contract as CombSub.forward except that the returned phase is sample-rate (B,T,1)
         (reference `ddsp/vocoder.py:423`).  `max_upsample_dim` is accepted and ignored: the bank kernel never
         materialises the (B,T,chunk) tensors the reference chunks to bound."""
-        self._refuse_training()
+        if self._training_graph():
+            ph, signal, harmonic, noise_out = _SynthTrainFn.apply(
+                self, units_frames, f0_frames, volume_frames, spk_id, spk_mix_dict, initial_phase, infer, noise,
+                noise_seed, *self.unit2ctrl.parameters())
+            return signal, ph.unsqueeze(-1), (harmonic, noise_out)
         ctx, ps = self._front(f0_frames, initial_phase, infer, COMB_NONE, want_phase=True)
         ctrl = self.unit2ctrl.forward_flat(units_frames, f0_frames, ps["phase_frames"], volume_frames, spk_id,
                                            spk_mix_dict)
@@ -246,6 +299,22 @@ class CombSubFast(_SynthBase):
         self.unit2ctrl = Unit2Control(n_unit, n_spk, {"harmonic_magnitude": nb, "harmonic_phase": nb,
                                                       "noise_magnitude": nb}, c)
 
+    _comb_mode = COMB_SINC_GATED
+    _front_wants = {}
+
+    def _train_forward(self, ctx, ctrl, ps, f0_frames, nargs):
+        B, Fr = ctrl.shape[0], ctrl.shape[1]
+        nz, exc, seed = nargs
+        signal = ctx.spectral_ola(ctrl.reshape(B * Fr, -1), ps["comb"], nz, exc, seed, B, Fr, self._hop)
+        return (signal,), (ps["comb"],)
+
+    def _train_backward(self, ctx, ctrl, saved, f0_frames, nargs, d_outs):
+        (comb,) = saved
+        B, Fr = ctrl.shape[0], ctrl.shape[1]
+        nz, exc, seed = nargs
+        return ctx.spectral_ola_bwd(ctrl.reshape(B * Fr, -1), comb, nz, exc, seed, _sum_grads(comb, *d_outs), B, Fr,
+                                    self._hop)
+
     def synth_from_ctrl(self, ctx, ctrl, comb, noise=None, noise_seed=None):
         B, Fr = ctrl.shape[0], ctrl.shape[1]
         nz, exc, seed = self._noise_args(noise, noise_seed)
@@ -255,7 +324,10 @@ class CombSubFast(_SynthBase):
                 infer=True, noise=None, noise_seed=None, **kwargs):
         """Returns (signal, phase_frames (B,Fr,1), (signal, signal)) - the same tensor three times, like the
         reference (`ddsp/vocoder.py:492`)."""
-        self._refuse_training()
+        if self._training_graph():
+            pf, signal = _SynthTrainFn.apply(self, units_frames, f0_frames, volume_frames, spk_id, spk_mix_dict,
+                                             initial_phase, infer, noise, noise_seed, *self.unit2ctrl.parameters())
+            return signal, pf.unsqueeze(-1), (signal, signal)
         ctx, ps = self._front(f0_frames, initial_phase, infer, COMB_SINC_GATED)
         ctrl = self.unit2ctrl.forward_flat(units_frames, f0_frames, ps["phase_frames"], volume_frames, spk_id,
                                            spk_mix_dict)

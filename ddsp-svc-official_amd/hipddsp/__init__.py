@@ -61,6 +61,8 @@ SIGNATURES = {
     "ddsp_fir_from_ctrl_bwd": (_int, [_vp, _vp, _int, _vp, _i64, _int, _vp, _i64, _int, _vp, _vp, _i64]),
     "ddsp_sins_bank": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp, _i64, _i64, _int, _int, _vp]),
     "ddsp_spectral_ola": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _int, _u64, _i64, _i64, _int, _vp]),
+    "ddsp_sins_bank_bwd": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _i64, _i64, _int, _int, _vp, _i64]),
+    "ddsp_spectral_ola_bwd": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _int, _u64, _vp, _i64, _i64, _int, _vp, _i64]),
     "ddsp_rss_loss": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _c.POINTER(_int), _int, _f32, _f32, _vp, _vp]),
     "ddsp_sola": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp]),
     "ddsp_volume_gate": (_int, [_vp, _vp, _vp, _vp, _f32, _i64, _i64, _int]),
@@ -312,6 +314,18 @@ class Context:
         self.call("ddsp_spectral_ola", _ptr(ctrl2d), ctrl2d.shape[-1], _ptr(comb), _ptr(noise), int(excitation),
                   int(noise_seed), B, Fr, int(hop), _ptr(out))
         return out
+
+    def sins_bank_bwd(self, ctrl2d, col0, n_harmonics, f0_frames, phase, d_out, B, Fr, hop, sr, d_ctrl2d):
+        f0 = f0_frames.reshape(-1).contiguous().float()
+        self.call("ddsp_sins_bank_bwd", _ptr(ctrl2d) + 4 * col0, ctrl2d.shape[-1], int(n_harmonics), _ptr(f0),
+                  _ptr(phase), _ptr(d_out.contiguous()), B, Fr, int(hop), int(sr), _ptr(d_ctrl2d) + 4 * col0,
+                  d_ctrl2d.shape[-1])
+
+    def spectral_ola_bwd(self, ctrl2d, comb, noise, excitation, noise_seed, d_out, B, Fr, hop):
+        d_ctrl = torch.empty_like(ctrl2d)
+        self.call("ddsp_spectral_ola_bwd", _ptr(ctrl2d), ctrl2d.shape[-1], _ptr(comb), _ptr(noise), int(excitation),
+                  int(noise_seed), _ptr(d_out.contiguous()), B, Fr, int(hop), _ptr(d_ctrl), d_ctrl.shape[-1])
+        return d_ctrl
 
     # -- a13 -----------------------------------------------------------------------------------
     def rss_loss(self, x_pred, x_true, n_ffts, alpha=1.0, eps=1e-7, want_grad=False):

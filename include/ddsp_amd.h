@@ -161,6 +161,15 @@ int ddsp_spectral_ola(ddsp_ctx* ctx, void* stream, const float* ctrl, int64_t ct
                       const float* noise, int excitation, uint64_t noise_seed, int64_t B, int64_t Fr, int hop,
                       float* out);
 
+/* Adjoints of a10 / a11 w.r.t. their control blocks (training of Sins / CombSubFast): d_out (B,T) -> d_ctrl written
+ * to the same column block layout as the forward reads, at row stride d_ctrl_ld. */
+int ddsp_sins_bank_bwd(ddsp_ctx* ctx, void* stream, const float* ctrl, int64_t ctrl_ld, int n_harmonics,
+                       const float* f0_frames, const float* phase, const float* d_out, int64_t B, int64_t Fr, int hop,
+                       int sr, float* d_ctrl, int64_t d_ctrl_ld);
+int ddsp_spectral_ola_bwd(ddsp_ctx* ctx, void* stream, const float* ctrl, int64_t ctrl_ld, const float* comb,
+                          const float* noise, int excitation, uint64_t noise_seed, const float* d_out, int64_t B,
+                          int64_t Fr, int hop, float* d_ctrl, int64_t d_ctrl_ld);
+
 /* ---- a13: random-scale spectral loss ---------------------------------------------------------- */
 /* replaces ddsp/loss.py:7-43 `RSSLoss.forward(x_pred, x_true)` for a given draw of scales: n_ffts_host holds the
  * n_scale values the reference draws with torch.randint(fft_min, fft_max) (ddsp/loss.py:39; the caller draws, so

@@ -77,3 +77,46 @@ def test_sharded_render_matches_unsharded(B):
     for r in range(world):
         assert got[r].shape == want.shape
         assert (got[r] - want).abs().max() < 1e-5        # every rank holds every utterance after the gather
+
+
+def _grad_worker(rank, world, port, q):
+    import sys
+    from conftest import PKG, ROOT
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import training
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(5)                       # identical parameters on every rank
+    params = [torch.nn.Parameter(torch.randn(7, 3)), torch.nn.Parameter(torch.randn(11)), torch.nn.Parameter(torch.randn(2, 2))]
+    torch.manual_seed(100 + rank)              # different gradients
+    for p in params[:2]:
+        p.grad = torch.randn_like(p)
+    local = [p.grad.clone() for p in params[:2]]
+    training.allreduce_gradients(params, world)
+    gathered = [torch.zeros(world, *g.shape) for g in local]
+    for g, l in zip(gathered, local):
+        dist.all_gather_into_tensor(g, l.unsqueeze(0).contiguous())
+    ok = all(torch.allclose(p.grad, g.mean(0), atol=1e-6) for p, g in zip(params[:2], gathered)) and params[2].grad is None
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_mean():
+    """Data-parallel training exchange: every rank ends with the mean gradient; parameters without a
+    gradient are skipped consistently."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(res.values())

@@ -15,13 +15,13 @@ def _rel(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
 
 
-def _oracle_step(sd0, cfg, inp, target, scales, lr=5e-4, wd=0.0, infer=False):
+def _oracle_step(sd0, cfg, inp, target, scales, lr=5e-4, wd=0.0, infer=False, kind="CombSub"):
     params = {k: v.clone().requires_grad_(True) for k, v in sd0.items()
               if v.is_floating_point() and "projection_matrix" not in k and k not in ("window",)}
     sd = dict(sd0)
     sd.update(params)
-    sig, _, _, _ = OS.combsub_forward(sd, cfg, inp["units"], inp["f0"], inp["volume"], inp["spk_id"], infer=infer,
-                                      noise=inp["noise"])
+    sig, _, _, _ = OS.FORWARD[kind](sd, cfg, inp["units"], inp["f0"], inp["volume"], inp["spk_id"], infer=infer,
+                                    noise=inp["noise"])
     loss = OL.rss_loss(sig, target, scales)
     loss.backward()
     opt = torch.optim.AdamW(list(params.values()), lr=lr, weight_decay=wd)
@@ -73,21 +73,21 @@ def test_combsub_train_step_matches_autograd(dev, lib_path, B, Fr):
     assert set(st.keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(st["step"]) == 1.0
 
 
-def test_combsub_gradients_exact_phase(dev, lib_path):
+@pytest.mark.parametrize("name,B,Fr", [("CombSub", 2, 172), ("Sins", 2, 60), ("CombSubFast", 2, 60), ("Sins256", 1, 20)])
+def test_gradients_exact_phase(dev, lib_path, name, B, Fr):
     """Same chain with infer=True (fp64 phase, no per-sample fp32 rounding): the device and oracle forwards agree to
     1e-6, so the parameter gradients must agree to the accuracy of the fp32 loss gradient (~1e-3)."""
     from ddsp.loss import RSSLoss
-    B, Fr = 2, 172
-    model, cfg = synthetic.build_model("CombSub", seed=13)
+    model, cfg = synthetic.build_model(name, seed=13)
     inp = synthetic.make_inputs(42, B, Fr)
     rng = np.random.Generator(np.random.PCG64(10))
     target = torch.from_numpy((0.1 * rng.standard_normal((B, Fr * 512))).astype(np.float32))
     scales = [300, 777, 1531, 2047]
-    loss_o, grads_o, _ = _oracle_step(model.state_dict(), cfg, inp, target, scales, infer=True)
+    loss_o, grads_o, _ = _oracle_step(model.state_dict(), cfg, inp, target, scales, infer=True, kind=cfg["type"])
     model = model.to(dev).train()
     crit = RSSLoss(256, 2048, 4, device=dev)
     d = {k: v.to(dev) for k, v in inp.items()}
-    sig, _, _ = model(d["units"], d["f0"], d["volume"], d["spk_id"], infer=True, noise=d["noise"])
+    sig, _, (hm, nz) = model(d["units"], d["f0"], d["volume"], d["spk_id"], infer=True, noise=d["noise"])
     crit.set_scales(scales)
     loss = crit(sig, target.to(dev))
     loss.backward()
@@ -124,7 +124,7 @@ def test_loss_decreases_over_steps(dev, lib_path):
     with torch.no_grad():   # a reachable target: the model's own output for perturbed weights
         tgt_model, _ = synthetic.build_model("CombSub", seed=3, device=dev)
         inp["audio"] = tgt_model(inp["units"], inp["f0"], inp["volume"], inp["spk_id"], noise=inp["noise"])[0]
-    opt = training.AdamW(model.parameters(), lr=2e-3, weight_decay=0.0)
+    opt = training.AdamW(model.parameters(), lr=3e-4, weight_decay=0.0)
     crit = RSSLoss(256, 2048, 4, device=dev)
     losses = [float(training.train_step(model, opt, crit, inp, scales=[256, 512, 1024, 2000])) for _ in range(12)]
-    assert all(np.isfinite(losses)) and min(losses) < 0.95 * losses[0] and losses[-1] < losses[0], losses
+    assert all(np.isfinite(losses)) and min(losses[1:]) < 0.98 * losses[0] and losses[-1] < losses[0], losses
