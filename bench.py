@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="CombSub", choices=["CombSub", "Sins256", "CombSubFast"])
+    ap.add_argument("--mode", default="synth", choices=["synth", "train"],
+                    help="synth (default, BASELINE configs[1]): forward only; train (configs[3]): one full training "
+                         "step per iteration, 32 clips per GPU, gradient all-reduce over RCCL")
     return ap.parse_args()
 
 
@@ -97,12 +100,30 @@ def main():
 
     gather = sharding.AudioGather(world, B_PER_GPU, T, dev) if world > 1 else None
 
-    def step(i):
-        with torch.no_grad():
-            sig, _, _ = model(inp["units"], inp["f0"], inp["volume"], inp["spk_id"], noise_seed=1000 + i)
-        if gather is not None:
-            gather.submit(sig)
-        return sig
+    if args.mode == "train":
+        import training
+        from ddsp.loss import RSSLoss
+        Bt = 32
+        inp = {k: v[:Bt].contiguous() for k, v in inp.items()}
+        inp["audio"] = 0.1 * torch.randn(Bt, T, device=dev, generator=torch.Generator(device=dev).manual_seed(7 + rank))
+        model.train()
+        opt = training.AdamW(model.parameters(), lr=5e-4, weight_decay=0.0)
+        crit = RSSLoss(256, 2048, 4, device=dev)
+        sg = torch.Generator().manual_seed(1234)      # the same n_fft draws on every rank
+        gather = None
+
+        def step(i):
+            scales = [int(v) for v in torch.randint(256, 2048, (4,), generator=sg)]
+            return training.train_step(model, opt, crit, inp, world=world, scales=scales)
+    else:
+        Bt = B_PER_GPU
+
+        def step(i):
+            with torch.no_grad():
+                sig, _, _ = model(inp["units"], inp["f0"], inp["volume"], inp["spk_id"], noise_seed=1000 + i)
+            if gather is not None:
+                gather.submit(sig)
+            return sig
 
     for i in range(args.warmup):
         step(i)
@@ -129,15 +150,19 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    total_samples = world * B_PER_GPU * T * args.steps
+    total_samples = world * Bt * T * args.steps
     value = total_samples / dt
     out = {
-        "metric": "audio samples/sec @44.1kHz CombSub synth" if args.model == "CombSub" else f"audio samples/sec @44.1kHz {args.model} synth",
+        "metric": ("audio samples/sec @44.1kHz CombSub synth" if args.model == "CombSub" else
+                   f"audio samples/sec @44.1kHz {args.model} synth") if args.mode == "synth" else
+                  f"audio samples/sec @44.1kHz {args.model} training step (fwd + RSS loss + bwd + AdamW)",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.model} 44.1 kHz, batch={B_PER_GPU}x2 s per GPU (Fr={FRAMES}, T={T}), "
-                               "units/f0/volume/spk_id -> audio, seeded random weights, in-kernel noise",
+        "config": {"workload": f"{args.model} 44.1 kHz, batch={Bt}x2 s per GPU (Fr={FRAMES}, T={T}), "
+                               + ("units/f0/volume/spk_id -> audio, seeded random weights, in-kernel noise"
+                                  if args.mode == "synth" else
+                                  "training step: forward(infer=False) + 4-scale RSS loss + backward + AdamW"),
                    "sharding": "utterances over ranks; all_gather of rendered audio overlapped on a side stream"
                    if world > 1 else "single GPU"},
         "x_realtime": value / SR,
@@ -162,7 +187,7 @@ def main():
         out["kernel_families_ms_per_step"] = {k: round(v["ms_total"] / nb, 4) for k, v in fam.items()}
         out["kernel_families_tflops"] = {k: round(v["flops_total"] / (v["ms_total"] * 1e-3) / 1e12, 2)
                                          for k, v in fam.items() if v["flops_total"] > 0}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.mode == "synth":
             out["cpu_baseline"] = cpu_baseline(seed)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -55,3 +55,51 @@ def test_volume_gate(ctx, dev):
     want2 = torch.cat([s2[i:i + 1] * RT.volume_gate(v2[i], -55, HOP) for i in range(3)])
     got2 = ctx.volume_gate_(s2.to(dev).clone(), torch.from_numpy(v2).to(dev), -55, HOP)
     assert torch.equal(got2.cpu(), want2)
+
+
+def test_offline_render_plumbing(dev, lib_path):
+    """BASELINE config #0 plumbing (main.py:143-174): per-slice model call, whole-file gate sliced per segment and
+    multiplied in place, silence padding and cross-fade of overlapping slices - device path vs the CPU oracle."""
+    import infer_offline
+    import synthetic
+    from ddsp.vocoder import DotDict
+    from oracle import synth as OS
+    model, cfg = synthetic.build_model("CombSubFast", seed=8)
+    sd = model.state_dict()
+    Fr = 173                                            # a 2 s file at 44.1 kHz / 512 (main.py:41-46)
+    inp = synthetic.make_inputs(91, 1, Fr)
+    inp["volume"][0, 60:75] = 1e-5                      # a silent stretch: the gate closes there
+    args = DotDict({"data": {"block_size": 512, "sampling_rate": 44100}})
+    # three slices: a gap before the second (silence padding) and an overlap before the third (cross-fade)
+    spans = [(0, 50), (55, 120), (118, 173)]
+    segments = [(a, inp["units"][:, a:b]) for a, b in spans]
+    # oracle pipeline
+    gate = RT.volume_gate(inp["volume"][0].numpy(), -60, 512)
+    result, current = np.zeros(0), 0
+    for a, b in spans:
+        with torch.no_grad():
+            out = OS.combsubfast_forward(sd, cfg, inp["units"][:, a:b], inp["f0"][:, a:b], inp["volume"][:, a:b],
+                                         inp["spk_id"], noise=inp["noise"][:, a * 512:b * 512])[0]
+        out = (out * gate[:, a * 512:b * 512]).squeeze().numpy()
+        silent = a * 512 - current
+        if silent >= 0:
+            result = np.append(np.append(result, np.zeros(silent)), out)
+        else:
+            result = RT.slice_cross_fade(result, out, current + silent)
+        current = current + silent + len(out)
+    # device pipeline with the same injected noise per slice
+    model = model.to(dev)
+
+    class Injected(torch.nn.Module):
+        def forward(self, units, f0, vol, spk_id=None, spk_mix_dict=None, **kw):
+            a = self.start.pop(0)
+            n = units.shape[1]
+            return model(units, f0, vol, spk_id, spk_mix_dict, noise=inp["noise"][:, a * 512:(a + n) * 512].to(dev))
+    inj = Injected()
+    inj.start = [a for a, _ in spans]
+    seg_dev = [(a, u.to(dev)) for a, u in segments]
+    got, sr_o = infer_offline.render(inj, args, seg_dev, inp["f0"].to(dev), inp["volume"].to(dev), inp["spk_id"].to(dev),
+                                     threshold_db=-60)
+    assert sr_o == 44100 and got.shape == result.shape
+    assert np.sqrt(np.mean((got - result) ** 2)) < 1e-4
+    assert np.abs(got[62 * 512:72 * 512]).max() == 0.0    # gated stretch is exactly silent
