@@ -8,6 +8,9 @@
 //   A_MODE = A_CONV3: A is X (rows x Cin); k = tap*Cin + c and A(m,k) = X[m + tap - 1][c] when frame
 //                 (m % Fr) + tap - 1 stays inside [0, Fr), else 0: a zero-padded k=3 Conv1d over the
 //                 frame axis without materialising im2col.
+//   A_MODE = A_FRAMES: rows are non-overlapping length-lda frames of B signals: row m lives at
+//                 A[(m / Fr)*sA_hi + (m % Fr)*lda] (Fr frames per signal, signals sA_hi apart) - the STFT framing of
+//                 the spectral loss without a copy.
 //   B_KC = true : B(k,n) = B[n*ldb + k]   (weights stored [N][K] like nn.Linear)
 //   B_KC = false: B(k,n) = B[k*ldb + n]   (stored K x N)
 //
@@ -26,7 +29,7 @@
 
 namespace gemm {
 
-enum { A_PLAIN = 0, A_CONV3 = 1 };
+enum { A_PLAIN = 0, A_CONV3 = 1, A_FRAMES = 2 };
 
 struct Args {
     const float* A;
@@ -69,7 +72,7 @@ __global__ void __launch_bounds__(64 * NW) kernel(Args g, Epi epi) {
     const int m0 = blockIdx.y * BM;
     const int n0 = blockIdx.x * BN;
     const int z = blockIdx.z;
-    const float* __restrict__ A = g.A + (int64_t)(z / g.zdiv) * g.sA_hi + (int64_t)(z % g.zdiv) * g.sA_lo;
+    const float* __restrict__ A = g.A + (A_MODE == A_FRAMES ? 0 : (int64_t)(z / g.zdiv) * g.sA_hi + (int64_t)(z % g.zdiv) * g.sA_lo);
     const float* __restrict__ B = g.B + (int64_t)(z / g.zdiv) * g.sB_hi + (int64_t)(z % g.zdiv) * g.sB_lo;
 
     // staging registers: BM*BK/256/4 float4 for A, BN*BK/256/4 for B
@@ -77,6 +80,10 @@ __global__ void __launch_bounds__(64 * NW) kernel(Args g, Epi epi) {
     static_assert(NA >= 1 && NB >= 1, "tile too small for the thread count");
     f32x4 ra[NA], rb[NB];
 
+    auto arow = [&](int m) -> const float* {
+        if (A_MODE == A_FRAMES) return A + (int64_t)(m / g.Fr) * g.sA_hi + (int64_t)(m % g.Fr) * g.lda;
+        return A + (int64_t)m * g.lda;
+    };
     // Interior tiles (the common case) take a branch-free path; edge tiles bounds-check every element.
     auto load_tiles = [&](int k0) {
         const bool k_full = (k0 + BK <= g.K);
@@ -97,9 +104,9 @@ __global__ void __launch_bounds__(64 * NW) kernel(Args g, Epi epi) {
                         if (f >= 0 && f < g.Fr) v = *(const f32x4_u*)(A + (int64_t)(m + tap - 1) * g.lda + c);
                     }
                 } else if (a_full) {
-                    v = *(const f32x4_u*)(A + (int64_t)m * g.lda + k);
+                    v = *(const f32x4_u*)(arow(m) + k);
                 } else if (m < g.M) {
-                    const float* p = A + (int64_t)m * g.lda + k;
+                    const float* p = arow(m) + k;
                     if (k + 3 < g.K) {
                         v = *(const f32x4_u*)p;
                     } else {

@@ -18,18 +18,8 @@ namespace {
 constexpr double kTwoPi = 6.283185307179586476925286766559;
 
 __global__ void stft_table_kernel(float* __restrict__ tab, int N, int ld) {
-    // norm = sqrt(sum_i hann_p(N)[i]^2) = sqrt(3N/8) for N >= 3 (exact identity); computed directly to stay generic
-    __shared__ double nrm_s;
-    if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < N; ++i) {
-            const double w = 0.5 - 0.5 * cos(kTwoPi * (double)i / (double)N);
-            s += w * w;
-        }
-        nrm_s = sqrt(s);
-    }
-    __syncthreads();
-    const double inv = 1.0 / nrm_s;
+    // norm = sqrt(sum_i hann_p(N)[i]^2) = sqrt(3N/8) (exact for N >= 3)
+    const double inv = 1.0 / sqrt(0.375 * (double)N);
     const int Mb = N / 2 + 1;
     const int64_t total = (int64_t)N * ld;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -134,14 +124,14 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(const float* __restrict_
     }
 }
 
-struct EpiGradFrames {  // grad[z*T + m*N + n] (+)= acc
+struct EpiGradFrames {  // grad[(m / F)*T + (m % F)*N + n] (+)= acc   (m runs over all B*F frames)
     float* grad;
     int64_t T;
-    int N;
+    int N, F;
     int accumulate;
     __device__ __forceinline__ float col(int) const { return 0.f; }
-    __device__ __forceinline__ void operator()(int z, int m, int n, float v, float) const {
-        float* p = grad + (int64_t)z * T + (int64_t)m * N + n;
+    __device__ __forceinline__ void operator()(int, int m, int n, float v, float) const {
+        float* p = grad + (int64_t)(m / F) * T + (int64_t)(m % F) * N + n;
         *p = accumulate ? *p + v : v;
     }
 };
@@ -196,14 +186,15 @@ extern "C" int ddsp_rss_loss(ddsp_ctx* ctx, void* stream, const float* x_pred, c
         const int F = (int)(T / N);
         const double weight = 1.0 / n_scale;
         hipLaunchKernelGGL(stft_table_kernel, dim3(1024), dim3(256), 0, st, tab, N, ld);
-        gemm::Args g = gemm::make(x_true, N, tab, ld, F, 2 * Mb, N);
-        g.zdiv = 1;
+        // all B*F frames form one M dimension (frame-remapped loader): full tiles even when F is 43
+        gemm::Args g = gemm::make(x_true, N, tab, ld, (int)(B * F), 2 * Mb, N);
+        g.Fr = F;
         g.sA_hi = T;
         EpiMag et{St, nullptr, F, Mb, ld, eps};
-        gemm::launch<true, false, gemm::A_PLAIN>(st, g, (int)B, et);
+        gemm::launch<true, false, gemm::A_FRAMES>(st, g, 1, et);
         g.A = x_pred;
         EpiMag ep{Sp, Xp, F, Mb, ld, eps};
-        gemm::launch<true, false, gemm::A_PLAIN>(st, g, (int)B, ep);
+        gemm::launch<true, false, gemm::A_FRAMES>(st, g, 1, ep);
         hipLaunchKernelGGL(loss_stats_kernel, dim3((unsigned)B), dim3(256), 0, st, St, Sp, (int64_t)F * Mb, stats);
         hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(64), 0, st, stats, (int)B, (double)B * F * Mb,
                            (double)alpha, weight, loss, s == 0 ? 1 : 0);
@@ -216,17 +207,16 @@ extern "C" int ddsp_rss_loss(ddsp_ctx* ctx, void* stream, const float* x_pred, c
                                Mb, ld, (double)alpha, weight, eps);
             const int64_t used = (int64_t)F * N;
             // dx = dX x T^T : A = dX (rows x 2Mb), B(k, n) = T[n][k]
-            gemm::Args gb = gemm::make(Xp, ld, tab, ld, F, N, 2 * Mb);
-            gb.sA_hi = (int64_t)F * ld;
+            gemm::Args gb = gemm::make(Xp, ld, tab, ld, (int)(B * F), N, 2 * Mb);
             if (s == 0) {
-                EpiGradFrames eg{grad_pred, T, N, 0};
-                gemm::launch<true, true, gemm::A_PLAIN>(st, gb, (int)B, eg);
+                EpiGradFrames eg{grad_pred, T, N, F, 0};
+                gemm::launch<true, true, gemm::A_PLAIN>(st, gb, 1, eg);
                 if (used < T) hipLaunchKernelGGL(zero_tail_kernel, dim3(64), dim3(256), 0, st, grad_pred, T, used, (int)B);
                 covered = used;
             } else {
                 // first fill any not-yet-covered stretch this scale reaches with zeros, then accumulate
-                EpiGradFrames eg{grad_pred, T, N, 1};
-                gemm::launch<true, true, gemm::A_PLAIN>(st, gb, (int)B, eg);
+                EpiGradFrames eg{grad_pred, T, N, F, 1};
+                gemm::launch<true, true, gemm::A_PLAIN>(st, gb, 1, eg);
                 if (used > covered) covered = used;
             }
             flops += 2.0 * B * F * (double)N * 2 * Mb;

@@ -178,9 +178,11 @@ class Unit2Control(nn.Module):
                 ("head_g", head.weight_g), ("head_v", head.weight_v), ("head_b", head.bias)]
         return out
 
-    def backward_flat(self, units, f0, phase, volume, spk_id, spk_mix_dict, d_ctrl):
-        """Gradients of every parameter for an upstream d_ctrl (B,Fr,n_out): {parameter tensor: gradient tensor}."""
-        ctx = hipddsp.context_for(units.device)
+    def backward_flat(self, units, f0, phase, volume, spk_id, spk_mix_dict, d_ctrl, ctx=None):
+        """Gradients of every parameter for an upstream d_ctrl (B,Fr,n_out): {parameter tensor: gradient tensor}.
+        `ctx`: the context of the forward call (autograd runs backward on its own thread; reusing the forward's
+        context keeps one scratch arena and one profiler per model call)."""
+        ctx = ctx or hipddsp.context_for(units.device)
         w, keep = self._weights_struct()
         g = hipddsp.U2CWeights()
         grads = {}

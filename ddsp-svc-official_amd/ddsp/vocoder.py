@@ -120,7 +120,7 @@ class _SynthTrainFn(torch.autograd.Function):
         B, Fr = ctrl.shape[0], ctrl.shape[1]
         d_ctrl = model._train_backward(ctx, ctrl, saved, f0_frames, nargs, d_outs)
         grads = model.unit2ctrl.backward_flat(units, f0_frames, phase_frames, volume, spk_id, spk_mix_dict,
-                                              d_ctrl.reshape(B, Fr, -1))
+                                              d_ctrl.reshape(B, Fr, -1), ctx=ctx)
         fctx.saved = None
         return (None,) * 10 + tuple(grads.get(p) for p in model.unit2ctrl.parameters())
 

@@ -102,4 +102,4 @@ def test_offline_render_plumbing(dev, lib_path):
                                      threshold_db=-60)
     assert sr_o == 44100 and got.shape == result.shape
     assert np.sqrt(np.mean((got - result) ** 2)) < 1e-4
-    assert np.abs(got[62 * 512:72 * 512]).max() == 0.0    # gated stretch is exactly silent
+    assert np.abs(got[64 * 512:70 * 512]).max() == 0.0    # 9-frame dilation: frames 64..70 of the 60..74 stretch are closed
