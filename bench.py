@@ -30,7 +30,25 @@ SR = 44100
 BYTES_PER_SAMPLE_API = 6.02   # units 256*4 + f0 4 + volume 4 in, 512*4 + 4 out per frame
 PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 DOMINANT = "u2c_gemm_linear"          # kernel family with the largest share of the step (profiles/)
-DOMINANT_KERNEL = "gemm::kernel<...,A_PLAIN> (fp32 MFMA 32x32x2), Linear / 1x1-conv layers of unit2ctrl"
+DOMINANT_KERNEL = "gemm::kernel_dma<128,64,...> (persistent LDS-DMA fp32 MFMA 32x32x2 GEMM), Linear / 1x1-conv layers of unit2ctrl"
+
+
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH 'HBM'; tools/pmc_traffic.py).  PMC collection
+    needs the profiler around the process, so bench.py reads the last committed measurement instead of taking it
+    live; None when the file is absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_per_launch.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    tot = n = 0.0
+    for k, v in d.items():
+        if "kernel_dma" in k:
+            tot += v["hbm_bytes_per_launch"] * v["launches_sampled"]
+            n += v["launches_sampled"]
+    return tot / n if n else None
 
 
 def parse():
@@ -182,7 +200,8 @@ def main():
         achieved = dom["flops_total"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
         out["roofline"] = {"kernel": DOMINANT_KERNEL, "bound": "mfma", "achieved": achieved,
                            "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F32_TFLOPS,
-                           "traffic": None, "avg_launch_ms": avg_ms, "launches": dom["launches"],
+                           "traffic": measured_traffic(), "avg_launch_ms": avg_ms, "launches": dom["launches"],
+                           "algorithmic_bytes_per_launch": dom["bytes_total"] / dom["launches"],
                            "algorithmic_flops_per_launch": dom["flops_total"] / dom["launches"]}
         out["kernel_families_ms_per_step"] = {k: round(v["ms_total"] / nb, 4) for k, v in fam.items()}
         out["kernel_families_tflops"] = {k: round(v["flops_total"] / (v["ms_total"] * 1e-3) / 1e12, 2)

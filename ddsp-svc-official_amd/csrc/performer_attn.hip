@@ -1,0 +1,228 @@
+// a4 (attention part): fused softmax-kernel feature maps + linear attention, one wavefront per work item, no
+// feature-map round trip through HBM.
+//
+// Replaces, for inference, the chain  [k P^T GEMM -> exp pass -> key sums -> k'^T v GEMM]  and
+// [q P^T GEMM -> max/exp pass -> 1/D pass -> q' ctx GEMM]  of ddsp/pcmer.py:69-77,123-159 (unit2ctrl.hip keeps
+// the unfused chain for training, whose backward needs q' and k').  The 94 MB q'/k' matrices per layer never
+// exist: a 32 x 32 tile of projected values lives in the MFMA accumulator, is exponentiated in place and is fed
+// straight back as the next product's operand (accumulator rows = the index the next product sums over):
+//   K kernel, item (b, h, feature tile jt): for each 32-frame tile:  S = k_tile P_jt^T  (frames x features, lane =
+//     feature), k' = r*exp(dn*S - diag + eps), ks += column sums, ctx_jt (32 features x 64) += k'^T v_tile where
+//     accumulator register r of lane half h IS the A operand of k-step (frame row(r,h)).
+//   Q kernel, item (b, h, frame tile ft): S^T = P q_tile^T for all 9 feature tiles (features x frames, lane = frame),
+//     row max = max over registers (+ one cross-half shuffle), q' in place, D = q'.ks, out^T (64 x 32 frames) +=
+//     ctx^T q' with the accumulator registers as B operands; out / D is transposed through 8 KB of LDS so the
+//     (frame, head) rows leave as 256-byte segments.
+// Operands come straight from L2 into registers with the permuted-k trick (lane half h owns k = 32h..32h+31 of a
+// 64-long row: eight 16-byte loads), so there is no LDS staging and no barrier.  All arithmetic fp32 (MFMA 32x32x2).
+#include "performer_attn.h"
+
+namespace {
+
+constexpr int H = 8, DH = 64, INNER = 512, NF = 266, LDF = 268, NJT = 9;
+constexpr float DN = 0.35355339059327373f;     // 64^-0.25
+constexpr float RATIO = 0.06131393394849658f;  // 266^-0.5
+
+__device__ __forceinline__ int acc_row(int r, int kh) { return (r & 3) + 8 * (r >> 2) + 4 * kh; }
+// exp through the hardware exp2 (v_exp_f32, ~1 ulp): 2 instructions instead of ~15; relative error ~1e-7*|x|, far
+// inside the tolerance of the positive random features (their arguments are O(10))
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+
+// 32 consecutive floats of a 64-float row (the half this lane owns), zero when the row is out of range
+__device__ __forceinline__ void load_half_row(const float* __restrict__ row, bool valid, float (&dst)[32]) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (valid) v = *(const f32x4*)(row + 4 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[4 * c + e] = v[e];
+    }
+}
+
+__global__ void __launch_bounds__(64) performer_kv_kernel(const float* __restrict__ k, const float* __restrict__ v,
+                                                          const float* __restrict__ P, int Fr, float* __restrict__ ctx,
+                                                          float* __restrict__ ks) {
+    // 1-D grid, XCD-aware: workgroups id and id+8 share an XCD (and its L2), so the NJT feature tiles of one
+    // (utterance, head) - which all re-read the same k and v rows - are dealt to ONE XCD group (id & 7)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int jt = slot % NJT, bh = (slot / NJT) * 8 + xcd, b = bh / H, h = bh % H;
+    const int lane = threadIdx.x, jl = lane & 31, kh = lane >> 5;
+    const int j = 32 * jt + jl;
+    float pb[32];
+    load_half_row(P + (int64_t)j * DH + 32 * kh, j < NF, pb);
+    f32x16 c0, c1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.f;
+    float ksum = 0.f;
+    const int n_ft = (Fr + 31) / 32;
+    const float* kb = k + ((int64_t)b * Fr) * INNER + h * DH + 32 * kh;
+    const float* vb = v + ((int64_t)b * Fr) * INNER + h * DH + jl;
+    // lane-constant byte offsets of the 16 frames this lane half feeds to the second product
+    int voff[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) voff[r] = acc_row(r, kh) * INNER;
+    // one frame tile: `cur` holds its k rows, `nxt` receives the next tile's (register ping-pong, no copies)
+    auto tile = [&](int ft, float (&cur)[32], float (&nxt)[32]) {
+        float v0[16], v1[16];
+        const float* vt = vb + (int64_t)(32 * ft) * INNER;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = 32 * ft + acc_row(r, kh) < Fr;
+            v0[r] = ok ? vt[voff[r]] : 0.f;
+            v1[r] = ok ? vt[voff[r] + 32] : 0.f;
+        }
+        float ss = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) ss = fmaf(cur[s], cur[s], ss);
+        ss += __shfl_xor(ss, 32, 64);
+        const float diag = ss * 0.5f * (DN * DN);   // of frame 32*ft + jl, known to lanes jl and jl+32
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) S = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[s], pb[s], S, 0, 0, 0);
+        const int nf = 32 * (ft + 1) + jl;
+        load_half_row(kb + (int64_t)nf * INNER, (ft + 1 < n_ft) && nf < Fr, nxt);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, kh);
+            const float dg = __shfl(diag, row, 64);
+            const bool ok = (32 * ft + row < Fr) && (j < NF);
+            const float kf = ok ? RATIO * fast_exp((DN * S[r] - dg) + 1e-4f) : 0.f;
+            ksum += kf;
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf, v0[r], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf, v1[r], c1, 0, 0, 0);
+        }
+    };
+    float ka[32], kc[32];
+    load_half_row(kb + (int64_t)jl * INNER, jl < Fr, ka);
+    for (int ft = 0; ft < n_ft; ft += 2) {
+        tile(ft, ka, kc);
+        if (ft + 1 < n_ft) tile(ft + 1, kc, ka);
+    }
+    ksum += __shfl_xor(ksum, 32, 64);
+    if (kh == 0 && j < LDF) ks[(int64_t)bh * LDF + j] = (j < NF) ? ksum : 0.f;
+    float* cd = ctx + (int64_t)bh * NF * DH;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int f = 32 * jt + acc_row(r, kh);
+        if (f < NF) {
+            cd[(int64_t)f * DH + jl] = c0[r];
+            cd[(int64_t)f * DH + 32 + jl] = c1[r];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) performer_q_kernel(const float* __restrict__ q, const float* __restrict__ P,
+                                                         const float* __restrict__ ctx, const float* __restrict__ ks,
+                                                         int Fr, int n_ft, float* __restrict__ attn) {
+    __shared__ float tile[32 * 65];
+    // XCD-aware 1-D grid (see performer_kv_kernel): the frame tiles of one (utterance, head) share ctx / ks
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int ft = slot % n_ft, bh = (slot / n_ft) * 8 + xcd, b = bh / H, h = bh % H;
+    const int lane = threadIdx.x, jl = lane & 31, kh = lane >> 5;
+    const int frame = 32 * ft + jl;
+    float qb[32];
+    load_half_row(q + ((int64_t)b * Fr + frame) * INNER + h * DH + 32 * kh, frame < Fr, qb);
+    float ss = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) ss = fmaf(qb[s], qb[s], ss);
+    ss += __shfl_xor(ss, 32, 64);
+    const float diag = ss * 0.5f * (DN * DN);
+    f32x16 S[NJT];
+    float pa[32];
+    load_half_row(P + (int64_t)jl * DH + 32 * kh, true, pa);
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt) {
+        float pn[32];
+        const int jn = 32 * (jt + 1) + jl;
+        load_half_row(P + (int64_t)jn * DH + 32 * kh, (jt + 1 < NJT) && jn < NF, pn);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[jt][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) S[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s], qb[s], S[jt], 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 32; ++s) pa[s] = pn[s];
+    }
+    // row maximum over the 266 real features of this lane's frame
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (32 * jt + acc_row(r, kh) < NF) mx = fmaxf(mx, DN * S[jt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float* ksr = ks + (int64_t)bh * LDF;
+    const float* cd = ctx + (int64_t)bh * NF * DH + jl;
+    float D = 0.f;
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+    // ctx / ks operands of one feature tile are fetched together (48 loads in flight), one tile ahead of their use,
+    // so the L2 latency is paid once per tile instead of once per accumulator register
+    float a0[16], a1[16], kv[16];
+    auto fetch = [&](int jt, float (&x0)[16], float (&x1)[16], float (&xk)[16]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = 32 * jt + acc_row(r, kh);
+            const bool ok = (jt < NJT) && f < NF;
+            x0[r] = ok ? cd[(int64_t)f * DH] : 0.f;
+            x1[r] = ok ? cd[(int64_t)f * DH + 32] : 0.f;
+            xk[r] = ok ? ksr[f] : 0.f;
+        }
+    };
+    fetch(0, a0, a1, kv);
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt) {
+        float n0[16], n1[16], nk[16];
+        fetch(jt + 1, n0, n1, nk);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = 32 * jt + acc_row(r, kh);
+            const bool ok = f < NF;
+            const float u = ok ? RATIO * (fast_exp((DN * S[jt][r] - diag) - mx) + 1e-4f) : 0.f;
+            D = fmaf(u, kv[r], D);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[r], u, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], u, o1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            a0[r] = n0[r];
+            a1[r] = n1[r];
+            kv[r] = nk[r];
+        }
+    }
+    D += __shfl_xor(D, 32, 64);
+    const float dinv = 1.0f / (D + 1e-8f);
+    // o[r] = out^T[e = acc_row(r,kh) (+32)][frame jl]: transpose through LDS, leave as rows of 64 floats
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int e = acc_row(r, kh);
+        tile[jl * 65 + e] = o0[r] * dinv;
+        tile[jl * 65 + 32 + e] = o1[r] * dinv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = lane + 64 * i;   // 512 float4 = 32 rows x 16
+        const int row = idx >> 4, c4 = (idx & 15) * 4;
+        const int fr = 32 * ft + row;
+        if (fr < Fr) {
+            f32x4 o = {tile[row * 65 + c4], tile[row * 65 + c4 + 1], tile[row * 65 + c4 + 2], tile[row * 65 + c4 + 3]};
+            *(f32x4*)(attn + ((int64_t)b * Fr + fr) * INNER + h * DH + c4) = o;
+        }
+    }
+}
+
+}  // namespace
+
+void performer_kv(hipStream_t st, const float* k, const float* v, const float* P, int B, int Fr, float* ctx, float* ks) {
+    // B*H is a multiple of 8, so the XCD-aware decode of the 1-D grid covers every (head, tile) exactly once
+    hipLaunchKernelGGL(performer_kv_kernel, dim3((unsigned)(NJT * B * H)), dim3(64), 0, st, k, v, P, Fr, ctx, ks);
+}
+
+void performer_q(hipStream_t st, const float* q, const float* P, const float* ctx, const float* ks, int B, int Fr,
+                 float* attn) {
+    const int n_ft = (Fr + 31) / 32;
+    hipLaunchKernelGGL(performer_q_kernel, dim3((unsigned)(n_ft * B * H)), dim3(64), 0, st, q, P, ctx, ks, Fr, n_ft, attn);
+}

@@ -11,6 +11,7 @@
 // row-wise exp pass.  Everything else (GroupNorm, LayerNorm, GLU, depthwise k=31 conv + SiLU, embeddings,
 // weight-norm) is small fused elementwise / row-reduction kernels.
 #include "gemm_f32.h"
+#include "performer_attn.h"
 
 namespace {
 
@@ -832,45 +833,53 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
             PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * INNER * D, 4.0 * M * (D + INNER),
                  (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
         }
-        {   // random-feature projections: (M*8, 64) x (266, 64)^T
-            gemm::Args g = gemm::make(b.q, DH, L.proj, DH, (int)M8, NF, DH);
-            gemm::EpiStore e{b.qf, LDF, nullptr, 1, 0, 0};
-            PROF(PF_U2C_GEMM_FEAT, 2.0 * M8 * NF * DH, 4.0 * M8 * (DH + NF),
-                 (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
-            g.A = b.k;
-            e.C = b.kf;
-            PROF(PF_U2C_GEMM_FEAT, 2.0 * M8 * NF * DH, 4.0 * M8 * (DH + NF),
-                 (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
-        }
-        PROF(PF_U2C_ROWWISE, 0, 4.0 * M8 * (2 * NF + DH),
-             hipLaunchKernelGGL(feature_map_kernel<true>, dim3(rows8_g), dim3(256), 0, st, b.qf, b.q, M8));
-        PROF(PF_U2C_ROWWISE, 0, 4.0 * M8 * (2 * NF + DH),
-             hipLaunchKernelGGL(feature_map_kernel<false>, dim3(rows8_g), dim3(256), 0, st, b.kf, b.k, M8));
-        PROF(PF_U2C_ROWWISE, 0, 4.0 * M8 * NF,
-             hipLaunchKernelGGL(key_sum_kernel, dim3((unsigned)(B * H)), dim3(320), 0, st, b.kf, (int)Fr, b.ks));
-        {   // ctx[b,h] (266 x 64) = k'^T v : A stored [n][j] (K x M), B stored [n][e] (K x N)
-            gemm::Args g = gemm::make(b.kf, (int64_t)H * LDF, b.v, INNER, NF, DH, (int)Fr);
-            g.zdiv = H;
-            g.sA_hi = (int64_t)Fr * H * LDF;
-            g.sA_lo = LDF;
-            g.sB_hi = (int64_t)Fr * INNER;
-            g.sB_lo = DH;
-            gemm::EpiStore e{b.cx, DH, nullptr, 1, (int64_t)NF * DH, 0};
-            PROF(PF_U2C_GEMM_CTX, 2.0 * M8 * NF * DH, 4.0 * M8 * (NF + DH),
-                 (gemm::launch_tile<64, 64, false, false, gemm::A_PLAIN>(st, g, (int)(B * H), e)));
-        }
-        PROF(PF_U2C_ROWWISE, 0, 4.0 * M8 * NF,
-             hipLaunchKernelGGL(attn_denominator_kernel, dim3(rows8_g), dim3(256), 0, st, b.qf, b.ks, (int)Fr, M8, b.dinv));
-        {   // out[b,n,h,:] = dinv * (q'[b,n,h,:] ctx[b,h])
-            gemm::Args g = gemm::make(b.qf, (int64_t)H * LDF, b.cx, DH, (int)Fr, DH, NF);
-            g.zdiv = H;
-            g.sA_hi = (int64_t)Fr * H * LDF;
-            g.sA_lo = LDF;
-            g.sB_hi = (int64_t)H * NF * DH;
-            g.sB_lo = (int64_t)NF * DH;
-            EpiAttnOut e{b.attn, b.dinv, (int)Fr};
-            PROF(PF_U2C_GEMM_ATTNOUT, 2.0 * M8 * NF * DH, 4.0 * M8 * (NF + DH),
-                 (gemm::launch_tile<64, 64, true, false, gemm::A_PLAIN>(st, g, (int)(B * H), e)));
+        if (!b.pre) {
+            // inference: fused feature maps + linear attention (performer_attn.hip); q'/k' never reach HBM
+            PROF(PF_U2C_GEMM_CTX, 4.0 * M8 * NF * DH, 4.0 * M * 2 * INNER,
+                 performer_kv(st, b.k, b.v, L.proj, (int)B, (int)Fr, b.cx, b.ks));
+            PROF(PF_U2C_GEMM_ATTNOUT, 4.0 * M8 * NF * DH, 4.0 * M * 2 * INNER,
+                 performer_q(st, b.q, L.proj, b.cx, b.ks, (int)B, (int)Fr, b.attn));
+        } else {
+            {   // random-feature projections: (M*8, 64) x (266, 64)^T
+                gemm::Args g = gemm::make(b.q, DH, L.proj, DH, (int)M8, NF, DH);
+                gemm::EpiStore e{b.qf, LDF, nullptr, 1, 0, 0};
+                PROF(PF_U2C_GEMM_FEAT, 2.0 * M8 * NF * DH, 4.0 * M8 * (DH + NF),
+                     (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
+                g.A = b.k;
+                e.C = b.kf;
+                PROF(PF_U2C_GEMM_FEAT, 2.0 * M8 * NF * DH, 4.0 * M8 * (DH + NF),
+                     (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
+            }
+            PROF(PF_U2C_ROWWISE, 0, 4.0 * M8 * (2 * NF + DH),
+                 hipLaunchKernelGGL(feature_map_kernel<true>, dim3(rows8_g), dim3(256), 0, st, b.qf, b.q, M8));
+            PROF(PF_U2C_ROWWISE, 0, 4.0 * M8 * (2 * NF + DH),
+                 hipLaunchKernelGGL(feature_map_kernel<false>, dim3(rows8_g), dim3(256), 0, st, b.kf, b.k, M8));
+            PROF(PF_U2C_ROWWISE, 0, 4.0 * M8 * NF,
+                 hipLaunchKernelGGL(key_sum_kernel, dim3((unsigned)(B * H)), dim3(320), 0, st, b.kf, (int)Fr, b.ks));
+            {   // ctx[b,h] (266 x 64) = k'^T v : A stored [n][j] (K x M), B stored [n][e] (K x N)
+                gemm::Args g = gemm::make(b.kf, (int64_t)H * LDF, b.v, INNER, NF, DH, (int)Fr);
+                g.zdiv = H;
+                g.sA_hi = (int64_t)Fr * H * LDF;
+                g.sA_lo = LDF;
+                g.sB_hi = (int64_t)Fr * INNER;
+                g.sB_lo = DH;
+                gemm::EpiStore e{b.cx, DH, nullptr, 1, (int64_t)NF * DH, 0};
+                PROF(PF_U2C_GEMM_CTX, 2.0 * M8 * NF * DH, 4.0 * M8 * (NF + DH),
+                     (gemm::launch_tile<64, 64, false, false, gemm::A_PLAIN>(st, g, (int)(B * H), e)));
+            }
+            PROF(PF_U2C_ROWWISE, 0, 4.0 * M8 * NF,
+                 hipLaunchKernelGGL(attn_denominator_kernel, dim3(rows8_g), dim3(256), 0, st, b.qf, b.ks, (int)Fr, M8, b.dinv));
+            {   // out[b,n,h,:] = dinv * (q'[b,n,h,:] ctx[b,h])
+                gemm::Args g = gemm::make(b.qf, (int64_t)H * LDF, b.cx, DH, (int)Fr, DH, NF);
+                g.zdiv = H;
+                g.sA_hi = (int64_t)Fr * H * LDF;
+                g.sA_lo = LDF;
+                g.sB_hi = (int64_t)H * NF * DH;
+                g.sB_lo = (int64_t)NF * DH;
+                EpiAttnOut e{b.attn, b.dinv, (int)Fr};
+                PROF(PF_U2C_GEMM_ATTNOUT, 2.0 * M8 * NF * DH, 4.0 * M8 * (NF + DH),
+                     (gemm::launch_tile<64, 64, true, false, gemm::A_PLAIN>(st, g, (int)(B * H), e)));
+            }
         }
         {
             gemm::Args g = gemm::make(b.attn, INNER, L.out_w, INNER, iM, D, INNER);
