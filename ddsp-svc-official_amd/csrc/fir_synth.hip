@@ -49,18 +49,37 @@ __global__ void __launch_bounds__(256) fir_act_kernel(int mode, const float* __r
     }
 }
 
-struct EpiDynWindow {  // ddsp/core.py:292-303 incl. its quirk: w>1 is zeroed BEFORE the cosine, w<-1 is not clamped
+// Real responses give filters that are even about tap n/2 (after the n/2 rotation), and the folded static Hann is even
+// too, so the GEMM only produces taps 0..n/2 and the epilogue mirrors them: tap k and tap n-k share the DFT value.
+// The dynamic raised-cosine is NOT even (ddsp/core.py:292-303: w>1 is zeroed BEFORE the cosine, w<-1 is not clamped),
+// so it is evaluated separately for both taps.
+struct EpiDynWindow {
     float* ir;
     int n;
     const float* f0;  // per row
     float sr15;       // 1.5 * sr as fp32
     __device__ __forceinline__ float col(int) const { return 0.f; }
-    __device__ __forceinline__ void operator()(int, int m, int k, float v, float) const {
-        const float hw = __fdiv_rn(sr15, __fadd_rn(f0[m], 1e-3f));
+    __device__ __forceinline__ float window(float hw, int k) const {
         float w = __fdiv_rn((float)(k - n / 2), hw);
         if (w > 1.0f) w = 0.0f;
-        const float win = __fdiv_rn(__fadd_rn(1.0f, cosf(__fmul_rn(3.14159274101257324f, w))), 2.0f);
-        ir[(int64_t)m * n + k] = __fmul_rn(v, win);
+        return __fdiv_rn(__fadd_rn(1.0f, cosf(__fmul_rn(3.14159274101257324f, w))), 2.0f);
+    }
+    __device__ __forceinline__ void operator()(int, int m, int k, float v, float) const {
+        const float hw = __fdiv_rn(sr15, __fadd_rn(f0[m], 1e-3f));
+        float* row = ir + (int64_t)m * n;
+        row[k] = __fmul_rn(v, window(hw, k));
+        if (k > 0 && k < n / 2) row[n - k] = __fmul_rn(v, window(hw, n - k));
+    }
+};
+
+struct EpiMirrorStore {  // row[k] = row[n-k] = acc
+    float* ir;
+    int n;
+    __device__ __forceinline__ float col(int) const { return 0.f; }
+    __device__ __forceinline__ void operator()(int, int m, int k, float v, float) const {
+        float* row = ir + (int64_t)m * n;
+        row[k] = v;
+        if (k > 0 && k < n / 2) row[n - k] = v;
     }
 };
 
@@ -174,13 +193,20 @@ extern "C" int ddsp_fir_from_ctrl(ddsp_ctx* ctx, void* stream, int mode, const f
     DDSP_LAUNCH_CHECK(ctx);
     ddsp_prof_begin(ctx, st, PF_FIR_DFT_GEMM);
 
-    gemm::Args g = gemm::make(act, lda, tab, ddsp_pad4(n), (int)rows, n, K);
-    if (mode == DDSP_FIR_DYNAMIC) {
-        EpiDynWindow epi{ir, n, f0_frames, 1.5f * (float)sr};
-        gemm::launch<true, false, gemm::A_PLAIN>(st, g, 1, epi);
-    } else {
+    if (mode == DDSP_FIR_ALLPASS) {
+        gemm::Args g = gemm::make(act, lda, tab, ddsp_pad4(n), (int)rows, n, K);
         gemm::EpiStore epi{ir, n, nullptr, 1, 0, 0};
         gemm::launch<true, false, gemm::A_PLAIN>(st, g, 1, epi);
+    } else {
+        // even filter: taps 0..n/2 from the GEMM, the rest mirrored by the epilogue
+        gemm::Args g = gemm::make(act, lda, tab, ddsp_pad4(n), (int)rows, n / 2 + 1, K);
+        if (mode == DDSP_FIR_DYNAMIC) {
+            EpiDynWindow epi{ir, n, f0_frames, 1.5f * (float)sr};
+            gemm::launch<true, false, gemm::A_PLAIN>(st, g, 1, epi);
+        } else {
+            EpiMirrorStore epi{ir, n};
+            gemm::launch<true, false, gemm::A_PLAIN>(st, g, 1, epi);
+        }
     }
     ddsp_prof_end(ctx, st, 2.0 * rows * (double)n * K, 4.0 * rows * (K + n));
     DDSP_LAUNCH_CHECK(ctx);

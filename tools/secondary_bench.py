@@ -1,0 +1,50 @@
+"""Secondary measurements for DESIGN.md: BASELINE configs #3 (Sins-256 additive bank), CombSubFast, #4 (train step),
+#5 (one real-time block: model forward on a 44 100-sample window + SOLA splice, B=1)."""
+import os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ddsp-svc-official_amd"))
+import torch
+import hipddsp, synthetic, realtime
+
+dev = torch.device("cuda:0")
+ctx = hipddsp.context_for(dev)
+out = {}
+
+def timeit(fn, n=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+B, Fr = 64, 172
+for name in ("CombSub", "Sins256", "CombSubFast", "Sins"):
+    model, cfg = synthetic.build_model(name, seed=1, device=dev)
+    inp = {k: v.to(dev) for k, v in synthetic.make_inputs(3, B, Fr, with_noise=False).items()}
+    with torch.no_grad():
+        t = timeit(lambda: model(inp["units"], inp["f0"], inp["volume"], inp["spk_id"], noise_seed=1))
+    out[f"{name}_forward_B64"] = {"ms": t * 1e3, "samples_per_s": B * Fr * 512 / t, "x_realtime": B * Fr * 512 / t / 44100}
+
+# additive-only bank of config #3 (H = 256)
+H = 256
+ctrl = torch.randn(B * Fr, H, device=dev) * 0.5
+f0 = torch.rand(B, Fr, 1, device=dev) * 700 + 65
+ps = ctx.phase_scan(f0, 512, 44100, None, True, 0, want_phase=True)
+t = timeit(lambda: ctx.sins_bank(ctrl, 0, H, f0, ps["phase"], B, Fr, 512, 44100))
+out["sins256_bank_only_B64"] = {"ms": t * 1e3, "samples_per_s": B * Fr * 512 / t, "hbm_GBps_algorithmic": 6.01 * B * Fr * 512 / t / 1e9}
+
+# real-time block: window of 44 100 samples at 44.1 kHz -> Fr = 87, B = 1, then SOLA splice
+model, cfg = synthetic.build_model("CombSub", seed=1, device=dev)
+inp = {k: v.to(dev) for k, v in synthetic.make_inputs(5, 1, 87, with_noise=False).items()}
+sp = realtime.Splicer(44100, 0.2, 0.04, dev)
+def rt():
+    with torch.no_grad():
+        sig = model(inp["units"], inp["f0"], inp["volume"], inp["spk_id"], noise_seed=2)[0]
+        ctx.volume_gate_(sig, inp["volume"], -60, 512)
+        return sp.push(sig[0])
+t = timeit(rt, n=50, warm=5)
+out["realtime_block_B1"] = {"ms_per_block": t * 1e3, "block_ms_of_audio": 200.0, "x_realtime": 0.2 / t}
+print(json.dumps(out, indent=1))
