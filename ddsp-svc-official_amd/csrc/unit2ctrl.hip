@@ -35,6 +35,28 @@ __global__ void pack_conv3_kernel(const float* __restrict__ w, int Cout, int Cin
     }
 }
 
+// q/k/v projections as ONE GEMM: rows [q_w; k_w; v_w] (3*512 x 256) and the three biases behind each other
+__global__ void __launch_bounds__(256) pack_qkv_kernel(const float* __restrict__ qw, const float* __restrict__ kw,
+                                                       const float* __restrict__ vw, const float* __restrict__ qb,
+                                                       const float* __restrict__ kb, const float* __restrict__ vb,
+                                                       float* __restrict__ w, float* __restrict__ bias) {
+    const int n = INNER * D;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 3 * n; i += gridDim.x * blockDim.x) {
+        const int which = i / n, j = i - which * n;
+        w[i] = which == 0 ? qw[j] : (which == 1 ? kw[j] : vw[j]);
+        if (j < INNER) bias[which * INNER + j] = which == 0 ? qb[j] : (which == 1 ? kb[j] : vb[j]);
+    }
+}
+
+struct EpiSplit3 {  // column block n / 512 selects the destination matrix (q, k or v), each (rows, 512)
+    float* out[3];
+    const float* bias;
+    __device__ __forceinline__ float col(int n) const { return bias[n]; }
+    __device__ __forceinline__ void operator()(int, int m, int n, float v, float cb) const {
+        out[n >> 9][(int64_t)m * INNER + (n & (INNER - 1))] = v + cb;
+    }
+};
+
 // W[o][:] = g[o] * v[o][:] / ||v[o]||_2   (old-style weight_norm, ddsp/unit2control.py:61); one wave per row
 __global__ void __launch_bounds__(256) weight_norm_kernel(const float* __restrict__ g, const float* __restrict__ v,
                                                           int n_out, int n_in, float* __restrict__ w) {
@@ -702,7 +724,7 @@ struct LayerBufs {
     float *x_in, *y, *q, *k, *v, *qf, *kf, *ks, *cx, *dinv, *attn, *x_mid, *y2, *g1, *glu, *pre, *dwo, *x_out;
 };
 struct U2CBufs {
-    float *w1, *w2, *wh, *t1, *t2, *gst, *y_final;
+    float *w1, *w2, *wh, *wqkv, *bqkv, *t1, *t2, *gst, *y_final;
     LayerBufs l[3];
 };
 
@@ -729,6 +751,8 @@ static void plan_forward(Arena& a, U2CBufs& bf, const ddsp_u2c_weights& w, int64
     bf.w1 = a.get((size_t)D * 3 * w.n_unit);
     bf.w2 = a.get((size_t)D * 3 * D);
     bf.wh = a.get((size_t)w.n_out * D);
+    bf.wqkv = a.get((size_t)3 * 3 * INNER * D);
+    bf.bqkv = a.get((size_t)3 * 3 * INNER);
     bf.t1 = a.get(M * D);
     bf.t2 = a.get(M * D);
     bf.gst = a.get((size_t)B * 4 * 2);
@@ -789,7 +813,11 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
     PROF(PF_U2C_PREP, 0, 8.0 * (n_w1 + n_w2 + n_wh),
          hipLaunchKernelGGL(pack_conv3_kernel, dim3(grid_for(n_w1)), dim3(256), 0, st, w.prenet_conv1_w, D, w.n_unit, bf.w1);
          hipLaunchKernelGGL(pack_conv3_kernel, dim3(grid_for(n_w2)), dim3(256), 0, st, w.prenet_conv2_w, D, D, bf.w2);
-         hipLaunchKernelGGL(weight_norm_kernel, dim3((w.n_out + 3) / 4), dim3(256), 0, st, w.head_g, w.head_v, w.n_out, D, bf.wh));
+         hipLaunchKernelGGL(weight_norm_kernel, dim3((w.n_out + 3) / 4), dim3(256), 0, st, w.head_g, w.head_v, w.n_out, D, bf.wh);
+         for (int l = 0; l < 3; ++l)
+             hipLaunchKernelGGL(pack_qkv_kernel, dim3(512), dim3(256), 0, st, w.layer[l].q_w, w.layer[l].k_w, w.layer[l].v_w,
+                                w.layer[l].q_b, w.layer[l].k_b, w.layer[l].v_b, bf.wqkv + (size_t)l * 3 * INNER * D,
+                                bf.bqkv + (size_t)l * 3 * INNER));
     // ---- prenet: conv k3 -> GroupNorm(4) -> LeakyReLU -> conv k3 ----
     {
         gemm::Args g = gemm::make(in.units, w.n_unit, bf.w1, 3 * w.n_unit, iM, D, 3 * w.n_unit);
@@ -824,13 +852,10 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         // -- x_mid = x_in + to_out(linear_attention(LN(x_in)))
         PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
              hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, b.x_in, L.norm_w, L.norm_b, M, b.y));
-        const float* pw[3] = {L.q_w, L.k_w, L.v_w};
-        const float* pb[3] = {L.q_b, L.k_b, L.v_b};
-        float* po[3] = {b.q, b.k, b.v};
-        for (int i = 0; i < 3; ++i) {
-            gemm::Args g = gemm::make(b.y, D, pw[i], D, iM, INNER, D);
-            gemm::EpiStore e{po[i], INNER, pb[i], 1, 0, 0};
-            PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * INNER * D, 4.0 * M * (D + INNER),
+        {
+            gemm::Args g = gemm::make(b.y, D, bf.wqkv + (size_t)l * 3 * INNER * D, D, iM, 3 * INNER, D);
+            EpiSplit3 e{{b.q, b.k, b.v}, bf.bqkv + (size_t)l * 3 * INNER};
+            PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * 3 * INNER * D, 4.0 * M * (D + 3 * INNER),
                  (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
         }
         if (!b.pre) {
