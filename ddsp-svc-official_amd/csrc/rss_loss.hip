@@ -51,14 +51,17 @@ struct EpiMag {  // S[z*F + m][f] = |X| + eps ; optionally keep X (interleaved r
     }
 };
 
-// one workgroup per utterance: d2, s2, l1 in fp64
+// LS_CHUNKS workgroups per utterance: partial d2, s2, l1 in fp64 (combined by loss_combine_kernel)
+constexpr int LS_CHUNKS = 16;
 __global__ void __launch_bounds__(256) loss_stats_kernel(const float* __restrict__ St, const float* __restrict__ Sp,
                                                          int64_t per_b, double* __restrict__ stats) {
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, ch = blockIdx.y;
     const float* t = St + (int64_t)b * per_b;
     const float* p = Sp + (int64_t)b * per_b;
+    const int64_t per = (per_b + LS_CHUNKS - 1) / LS_CHUNKS;
+    const int64_t i0 = ch * per, i1 = (i0 + per < per_b) ? i0 + per : per_b;
     double d2 = 0, s2 = 0, l1 = 0;
-    for (int64_t i = threadIdx.x; i < per_b; i += 256) {
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
         const float a = t[i], c = p[i];
         const float d = a - c, s = a + c;
         d2 += (double)d * d;
@@ -77,10 +80,28 @@ __global__ void __launch_bounds__(256) loss_stats_kernel(const float* __restrict
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        stats[b * 3 + 0] = red[0] + red[1] + red[2] + red[3];
-        stats[b * 3 + 1] = red[4] + red[5] + red[6] + red[7];
-        stats[b * 3 + 2] = red[8] + red[9] + red[10] + red[11];
+        double* o = stats + ((int64_t)b * LS_CHUNKS + ch) * 3;
+        o[0] = red[0] + red[1] + red[2] + red[3];
+        o[1] = red[4] + red[5] + red[6] + red[7];
+        o[2] = red[8] + red[9] + red[10] + red[11];
     }
+}
+
+// folds the chunk partials of every utterance into stats[b][0..2] (first chunk slot) in a fixed order
+__global__ void loss_fold_kernel(double* __restrict__ stats, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double d2 = 0, s2 = 0, l1 = 0;
+    for (int c = 0; c < LS_CHUNKS; ++c) {
+        const double* o = stats + ((int64_t)b * LS_CHUNKS + c) * 3;
+        d2 += o[0];
+        s2 += o[1];
+        l1 += o[2];
+    }
+    double* o = stats + (int64_t)b * LS_CHUNKS * 3;
+    o[0] = d2;
+    o[1] = s2;
+    o[2] = l1;
 }
 
 // loss += weight * (mean_b sqrt(d2/s2) + alpha * sum l1 / count)
@@ -89,8 +110,8 @@ __global__ void loss_combine_kernel(const double* __restrict__ stats, int B, dou
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double conv = 0.0, l1 = 0.0;
     for (int b = 0; b < B; ++b) {
-        conv += sqrt(stats[b * 3 + 0]) / sqrt(stats[b * 3 + 1]);
-        l1 += stats[b * 3 + 2];
+        conv += sqrt(stats[b * LS_CHUNKS * 3 + 0]) / sqrt(stats[b * LS_CHUNKS * 3 + 1]);
+        l1 += stats[b * LS_CHUNKS * 3 + 2];
     }
     const double v = weight * (conv / B + alpha * l1 / count);
     loss[0] = (first ? 0.f : loss[0]) + (float)v;
@@ -107,7 +128,7 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(const float* __restrict_
         const int b = (int)(i / per_b);
         const int64_t row = i / Mb;
         const int f = (int)(i % Mb);
-        const double rd = sqrt(stats[b * 3 + 0]), rs = sqrt(stats[b * 3 + 1]);
+        const double rd = sqrt(stats[b * LS_CHUNKS * 3 + 0]), rs = sqrt(stats[b * LS_CHUNKS * 3 + 1]);
         const float a = St[i], c = Sp[i];
         double g = 0.0;
         if (rd > 0.0) g += (-(double)(a - c) / (rd * rs)) / B;
@@ -166,7 +187,7 @@ extern "C" int ddsp_rss_loss(ddsp_ctx* ctx, void* stream, const float* x_pred, c
     const size_t s_f = (size_t)B * (size_t)(T / 2 + T / minN + 8);  // rows*Mb <= B*(T/2 + F)
     const size_t x_f = grad_pred ? (size_t)B * (size_t)(T + 4 * (T / minN) + 16) : 0;
     (void)rows_max;
-    int rc = ddsp_scratch_reserve_bytes(ctx, (tab_f + 2 * s_f + x_f) * sizeof(float) + (size_t)B * 3 * sizeof(double) + 8192);
+    int rc = ddsp_scratch_reserve_bytes(ctx, (tab_f + 2 * s_f + x_f) * sizeof(float) + (size_t)B * 16 * 3 * sizeof(double) + 8192);
     if (rc) return rc;
     ddsp_scratch_reset(ctx);
     float *tab, *St, *Sp, *Xp = nullptr;
@@ -175,7 +196,7 @@ extern "C" int ddsp_rss_loss(ddsp_ctx* ctx, void* stream, const float* x_pred, c
     if ((rc = ddsp_scratch_get(ctx, s_f * sizeof(float), (void**)&St))) return rc;
     if ((rc = ddsp_scratch_get(ctx, s_f * sizeof(float), (void**)&Sp))) return rc;
     if (grad_pred && (rc = ddsp_scratch_get(ctx, x_f * sizeof(float), (void**)&Xp))) return rc;
-    if ((rc = ddsp_scratch_get(ctx, (size_t)B * 3 * sizeof(double), (void**)&stats))) return rc;
+    if ((rc = ddsp_scratch_get(ctx, (size_t)B * LS_CHUNKS * 3 * sizeof(double), (void**)&stats))) return rc;
 
     ddsp_prof_begin(ctx, st, PF_RSS_LOSS);
     double flops = 0.0;
@@ -195,7 +216,8 @@ extern "C" int ddsp_rss_loss(ddsp_ctx* ctx, void* stream, const float* x_pred, c
         g.A = x_pred;
         EpiMag ep{Sp, Xp, F, Mb, ld, eps};
         gemm::launch<true, false, gemm::A_FRAMES>(st, g, 1, ep);
-        hipLaunchKernelGGL(loss_stats_kernel, dim3((unsigned)B), dim3(256), 0, st, St, Sp, (int64_t)F * Mb, stats);
+        hipLaunchKernelGGL(loss_stats_kernel, dim3((unsigned)B, LS_CHUNKS), dim3(256), 0, st, St, Sp, (int64_t)F * Mb, stats);
+        hipLaunchKernelGGL(loss_fold_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, stats, (int)B);
         hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(64), 0, st, stats, (int)B, (double)B * F * Mb,
                            (double)alpha, weight, loss, s == 0 ? 1 : 0);
         flops += 2.0 * 2.0 * B * F * (double)N * 2 * Mb;

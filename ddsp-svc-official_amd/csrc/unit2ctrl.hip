@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
 
 // Column sums over rows, optionally weighted per row: out_partial[chunk][c] = sum_{r in chunk} X[r][c] * w(r).
 // wmode: 0 none, 1 w = wsrc[r], 2 w = ln(1 + wsrc[r]/700), 3 w = wsrc[r]/pi     (the three side embeddings)
-constexpr int CS_CHUNKS = 64;
+constexpr int CS_CHUNKS = 32;
 __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ X, int64_t ld, int64_t rows,
                                                              int cols, const float* __restrict__ wsrc, int wmode,
                                                              float* __restrict__ partial) {
@@ -398,9 +398,16 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __rest
 __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __restrict__ partial, int nz, int64_t n,
                                                               float* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int z = 0; z < nz; ++z) s += partial[(int64_t)z * n + i];
-        out[i] = s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four independent chains keep the loads in flight
+        int z = 0;
+        for (; z + 3 < nz; z += 4) {
+            s0 += partial[(int64_t)z * n + i];
+            s1 += partial[(int64_t)(z + 1) * n + i];
+            s2 += partial[(int64_t)(z + 2) * n + i];
+            s3 += partial[(int64_t)(z + 3) * n + i];
+        }
+        for (; z < nz; ++z) s0 += partial[(int64_t)z * n + i];
+        out[i] = (s0 + s1) + (s2 + s3);
     }
 }
 
@@ -426,18 +433,22 @@ __global__ void __launch_bounds__(256) glu_bwd_kernel(const float* __restrict__ 
     }
 }
 
-// depthwise-conv weight gradient: partial[b][c][t] = sum_f dpre[b,f,c] * x[b, f+t-15, c]; block = (64 channels, utterance)
+// depthwise-conv weight gradient: partial[(b, chunk)][c][t] = sum_{f in chunk} dpre[b,f,c] * x[b, f+t-15, c];
+// block = (64 channels, utterance, frame chunk)
+constexpr int DWG_CHUNKS = 4;
 __global__ void __launch_bounds__(256) dwconv_wgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ x,
                                                            int Fr, float* __restrict__ partial) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int tg = threadIdx.x >> 6;  // taps tg, tg+4, ...
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, ch = blockIdx.z;
+    const int per = (Fr + DWG_CHUNKS - 1) / DWG_CHUNKS;
+    const int fa = ch * per, fb = (fa + per < Fr) ? fa + per : Fr;
     const float* dp = dpre + ((int64_t)b * Fr) * INNER + c;
     const float* xp = x + ((int64_t)b * Fr) * INNER + c;
     float acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    for (int f = 0; f < Fr; ++f) {
+    for (int f = fa; f < fb; ++f) {
         const float d = dp[(int64_t)f * INNER];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -449,7 +460,7 @@ __global__ void __launch_bounds__(256) dwconv_wgrad_kernel(const float* __restri
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int t = tg + 4 * i;
-        if (t < DWK) partial[((int64_t)b * INNER + c) * DWK + t] = acc[i];
+        if (t < DWK) partial[(((int64_t)b * DWG_CHUNKS + ch) * INNER + c) * DWK + t] = acc[i];
     }
 }
 
@@ -1021,7 +1032,7 @@ static int colsum(ddsp_ctx* ctx, hipStream_t st, const float* X, int64_t ld, int
                   int wmode, float* partial, float* out) {
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, CS_CHUNKS), dim3(256), 0, st, X, ld, rows, cols, wsrc,
                        wmode, partial);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(cols)), dim3(256), 0, st, partial, CS_CHUNKS, (int64_t)cols, out);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(cols, 64)), dim3(64), 0, st, partial, CS_CHUNKS, (int64_t)cols, out);
     DDSP_LAUNCH_CHECK(ctx);
     return DDSP_OK;
 }
@@ -1112,7 +1123,7 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
         dWh = a.get((size_t)NO * D);
         pk = a.get((size_t)D * 3 * (w.n_unit > D ? w.n_unit : D));
         xs = a.get((size_t)M * (w.n_unit > D ? w.n_unit : D));
-        dwpart = a.get((size_t)B * INNER * DWK);
+        dwpart = a.get((size_t)B * DWG_CHUNKS * INNER * DWK);
         gbst = a.get((size_t)B * 4 * 2);
         w2t = a.get((size_t)D * 3 * D);
     };
@@ -1150,8 +1161,8 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
         if ((rc = colsum(ctx, st, dX, D, M, D, nullptr, 0, cpart, GLP(cm_pw2_b)))) return rc;
         dgrad(st, dX, D, L.cm_pw2_w, D, INNER, M, dB512, false);                                   // d_dwo
         hipLaunchKernelGGL(silu_bwd_kernel, dim3(grid_for(M * INNER)), dim3(256), 0, st, b.pre, dB512, M * INNER, dB512);  // d_pre
-        hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(INNER / 64, (unsigned)B), dim3(256), 0, st, dB512, b.glu, (int)Fr, dwpart);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(INNER * DWK)), dim3(256), 0, st, dwpart, (int)B,
+        hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(INNER / 64, (unsigned)B, DWG_CHUNKS), dim3(256), 0, st, dB512, b.glu, (int)Fr, dwpart);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(INNER * DWK)), dim3(256), 0, st, dwpart, (int)B * DWG_CHUNKS,
                            (int64_t)INNER * DWK, GLP(cm_dw_w));
         if ((rc = colsum(ctx, st, dB512, INNER, M, INNER, nullptr, 0, cpart, GLP(cm_dw_b)))) return rc;
         hipLaunchKernelGGL((dwconv_kernel<false, true>), dim3(INNER / 256, (unsigned)(B * ((Fr + DW_RUN - 1) / DW_RUN))),
