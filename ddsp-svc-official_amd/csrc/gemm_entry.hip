@@ -24,7 +24,9 @@ extern "C" int ddsp_gemm_f32(ddsp_ctx* ctx, void* stream, const float* A, int64_
         DDSP_REQUIRE(ctx, a_k_contig && b_k_contig && gemm::dma_ok(g), "ddsp_gemm_f32: DMA tiles need row-major A, [N][K] B, K % 32 == 0, aligned rows");
         if (tile == 10) gemm::launch_dma<128, 64>(st, g, 1, e);
         else if (tile == 11) gemm::launch_dma<128, 128>(st, g, 1, e);
-        else gemm::launch_dma<256, 128>(st, g, 1, e);
+        else if (tile == 12) gemm::launch_dma<256, 128>(st, g, 1, e);
+        else if (tile == 13) gemm::launch_dma<128, 128, gemm::EpiStore, 2>(st, g, 1, e);
+        else gemm::launch_dma<128, 64, gemm::EpiStore, 2>(st, g, 1, e);
     } else if (a_k_contig && b_k_contig) {
         TILE(true, true)
     } else if (a_k_contig && !b_k_contig) {

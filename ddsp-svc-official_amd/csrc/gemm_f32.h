@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(64 * NW) kernel(Args g, Epi epi) {
 // address), so that the MFMA operand fetch - lane (i = l&31, h = l>>5) reads its 16 k-values 16h..16h+15 of row i
 // as four ds_read_b128 - is bank-conflict-free.  The MFMA k-order is permuted (step s of lane half h is
 // k = 16h + s) identically for A and B, which leaves the sum unchanged.
-template <int BM, int BN, class Epi>
+template <int BM, int BN, class Epi, int NS = 3>
 __global__ void __launch_bounds__(512) kernel_dma(Args g, Epi epi, int tiles_m, int tiles_n, int total_tiles) {
     constexpr int NW = 8, WGM = 4, WGN = 2;
     constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(512) kernel_dma(Args g, Epi epi, int tiles_m, 
     constexpr int PIECES = ROWS / 8;         // 1-KiB DMA pieces per stage
     constexpr int PPW = PIECES / NW;         // pieces per wave
     static_assert(PIECES % NW == 0, "stage must split evenly over the waves");
-    __shared__ __attribute__((aligned(1024))) float lds[3 * STAGE];
+    __shared__ __attribute__((aligned(1024))) float lds[NS * STAGE];   // NS-stage ring (NS-1 tiles in flight)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * (BM / WGM), wn = (wave & 1) * (BN / WGN);
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(512) kernel_dma(Args g, Epi epi, int tiles_m, 
     if (steps > 0) tile_src((int)blockIdx.x, src_cur);
     auto issue_next = [&]() {
         if (issued >= steps) return;
-        issue(src_cur, issue_kt, issued % 3);
+        issue(src_cur, issue_kt, issued % NS);
         ++issued;
         if (++issue_kt == nk) {
             issue_kt = 0;
@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(512) kernel_dma(Args g, Epi epi, int tiles_m, 
         }
     };
     issue_next();
-    issue_next();
+    if (NS > 2) issue_next();
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -374,14 +374,14 @@ __global__ void __launch_bounds__(512) kernel_dma(Args g, Epi epi, int tiles_m, 
     int kt = 0, tile_i = 0;
     for (int step = 0; step < steps; ++step) {
         // step has landed once at most the next step's pieces of THIS wave are still in flight ...
-        if (step + 1 < steps)
+        if (NS > 2 && step + 1 < steps)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // ... and every other wave says the same; the barrier also fences the reads of stage (step+2)%3 (step-1)
         __builtin_amdgcn_s_barrier();
         issue_next();  // step + 2
-        const float* st = lds + (step % 3) * STAGE;
+        const float* st = lds + (step % NS) * STAGE;
         f32x4 av[TM][4], bv[TN][4];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -441,16 +441,16 @@ inline bool dma_ok(const Args& g) {
            g.sA_hi % 4 == 0 && g.sA_lo % 4 == 0 && g.sB_hi % 4 == 0 && g.sB_lo % 4 == 0;
 }
 
-template <int BM, int BN, class Epi>
+template <int BM, int BN, class Epi, int NS = 3>
 inline void launch_dma(hipStream_t st, const Args& g, int batch, const Epi& epi) {
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
     const int total = tiles_m * tiles_n * batch;
-    // resident workgroups per CU by LDS (3 stages of (BM+BN) x 128 B), 8 waves each
-    constexpr int lds_bytes = 3 * (BM + BN) * 128;
+    // resident workgroups per CU by LDS (NS stages of (BM+BN) x 128 B), 8 waves each
+    constexpr int lds_bytes = NS * (BM + BN) * 128;
     constexpr int per_cu = (160 * 1024 / lds_bytes) < 2 ? (160 * 1024 / lds_bytes) : 2;
     int grid = 256 * per_cu;
     if (grid > total) grid = total;
-    hipLaunchKernelGGL((kernel_dma<BM, BN, Epi>), dim3(grid), dim3(512), 0, st, g, epi, tiles_m, tiles_n, total);
+    hipLaunchKernelGGL((kernel_dma<BM, BN, Epi, NS>), dim3(grid), dim3(512), 0, st, g, epi, tiles_m, tiles_n, total);
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC, int A_MODE, class Epi, int NW = 4>
@@ -472,7 +472,13 @@ inline void launch(hipStream_t st, const Args& g, int batch, const Epi& epi) {
     };
     if constexpr (A_KC && B_KC && A_MODE == A_PLAIN) {
         if (dma_ok(g) && blocks(128, 64) >= 256) {
-            launch_dma<128, 64, Epi>(st, g, batch, epi);
+            // 128x128 tiles (32 FLOP per staged byte, 2-stage ring, 2 workgroups per CU) when they still fill the
+            // 512 resident slots, or when N is so small that the 128x64 grid is half empty anyway; else 128x64
+            // tiles with the 3-stage ring (tools/gemm_ab.py: N=1024 86 vs 78, N=256 67-72 vs 65-68, N=512 59 vs 70)
+            if (blocks(128, 128) >= 512 || g.N <= 256)
+                launch_dma<128, 128, Epi, 2>(st, g, batch, epi);
+            else
+                launch_dma<128, 64, Epi, 3>(st, g, batch, epi);
             return;
         }
     }
