@@ -26,7 +26,9 @@ extern "C" int ddsp_gemm_f32(ddsp_ctx* ctx, void* stream, const float* A, int64_
         else if (tile == 11) gemm::launch_dma<128, 128>(st, g, 1, e);
         else if (tile == 12) gemm::launch_dma<256, 128>(st, g, 1, e);
         else if (tile == 13) gemm::launch_dma<128, 128, gemm::EpiStore, 2>(st, g, 1, e);
-        else gemm::launch_dma<128, 64, gemm::EpiStore, 2>(st, g, 1, e);
+        else if (tile == 14) gemm::launch_dma<128, 64, gemm::EpiStore, 2>(st, g, 1, e);
+        else if (tile == 20) gemm::launch_dma<128, 64, gemm::EpiStore, 3, 1>(st, g, 1, e);   // no MFMA (timing only)
+        else gemm::launch_dma<128, 64, gemm::EpiStore, 3, 2>(st, g, 1, e);                    // no DMA (timing only)
     } else if (a_k_contig && b_k_contig) {
         TILE(true, true)
     } else if (a_k_contig && !b_k_contig) {

@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(64 * NW) kernel(Args g, Epi epi) {
 // address), so that the MFMA operand fetch - lane (i = l&31, h = l>>5) reads its 16 k-values 16h..16h+15 of row i
 // as four ds_read_b128 - is bank-conflict-free.  The MFMA k-order is permuted (step s of lane half h is
 // k = 16h + s) identically for A and B, which leaves the sum unchanged.
-template <int BM, int BN, class Epi, int NS = 3>
+template <int BM, int BN, class Epi, int NS = 3, int ABLATE = 0>  // ABLATE (timing experiments only): 1 = no MFMA, 2 = no DMA
 __global__ void __launch_bounds__(512) kernel_dma(Args g, Epi epi, int tiles_m, int tiles_n, int total_tiles) {
     constexpr int NW = 8, WGM = 4, WGN = 2;
     constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(512) kernel_dma(Args g, Epi epi, int tiles_m, 
     if (steps > 0) tile_src((int)blockIdx.x, src_cur);
     auto issue_next = [&]() {
         if (issued >= steps) return;
-        issue(src_cur, issue_kt, issued % NS);
+        if (ABLATE != 2) issue(src_cur, issue_kt, issued % NS);
         ++issued;
         if (++issue_kt == nk) {
             issue_kt = 0;
@@ -397,14 +397,22 @@ __global__ void __launch_bounds__(512) kernel_dma(Args g, Epi epi, int tiles_m, 
 #pragma unroll
             for (int c = 0; c < 4; ++c) bv[j][c] = *(const f32x4*)(rp + 4 * ((4 * lh + c) ^ ((row >> 1) & 7)));
         }
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
+        if (ABLATE == 1) {
+            // keep the operand reads alive without the matrix pipe
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s >> 2][s & 3], bv[j][s >> 2][s & 3],
-                                                                     acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j][0] += av[i][0][0] + bv[j][3][3];
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s >> 2][s & 3], bv[j][s >> 2][s & 3],
+                                                                         acc[i][j], 0, 0, 0);
+        }
         if (++kt == nk) {
             // ---- epilogue of this tile (stores drain while the next tile's MFMAs run) ----
             const int tile = (int)blockIdx.x + tile_i * (int)gridDim.x;
@@ -441,7 +449,7 @@ inline bool dma_ok(const Args& g) {
            g.sA_hi % 4 == 0 && g.sA_lo % 4 == 0 && g.sB_hi % 4 == 0 && g.sB_lo % 4 == 0;
 }
 
-template <int BM, int BN, class Epi, int NS = 3>
+template <int BM, int BN, class Epi, int NS = 3, int ABLATE = 0>
 inline void launch_dma(hipStream_t st, const Args& g, int batch, const Epi& epi) {
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
     const int total = tiles_m * tiles_n * batch;
@@ -450,7 +458,7 @@ inline void launch_dma(hipStream_t st, const Args& g, int batch, const Epi& epi)
     constexpr int per_cu = (160 * 1024 / lds_bytes) < 2 ? (160 * 1024 / lds_bytes) : 2;
     int grid = 256 * per_cu;
     if (grid > total) grid = total;
-    hipLaunchKernelGGL((kernel_dma<BM, BN, Epi, NS>), dim3(grid), dim3(512), 0, st, g, epi, tiles_m, tiles_n, total);
+    hipLaunchKernelGGL((kernel_dma<BM, BN, Epi, NS, ABLATE>), dim3(grid), dim3(512), 0, st, g, epi, tiles_m, tiles_n, total);
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC, int A_MODE, class Epi, int NW = 4>
