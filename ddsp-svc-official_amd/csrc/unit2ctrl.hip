@@ -964,7 +964,7 @@ static int check_inputs(ddsp_ctx* ctx, const ddsp_u2c_weights* wp, const float* 
                         const int64_t* mix_ids_host, const float* mix_w_host, int n_mix, int64_t B, int64_t Fr,
                         U2CInputs& in) {
     DDSP_REQUIRE(ctx, ctx && wp && units && f0_frames && phase_frames && volume, "ddsp_unit2ctrl: null argument");
-    DDSP_REQUIRE(ctx, B >= 0 && Fr >= 1 && B * Fr < (1 << 26), "ddsp_unit2ctrl: bad shape");
+    DDSP_REQUIRE(ctx, B >= 0 && B <= 4096 && Fr >= 1 && B * Fr < (1 << 26), "ddsp_unit2ctrl: bad shape (B <= 4096 per call)");
     DDSP_REQUIRE(ctx, n_mix >= 0 && n_mix <= 16, "ddsp_unit2ctrl: at most 16 mixed speakers");
     DDSP_REQUIRE(ctx, n_mix > 0 || (spk_id && (n_spk_id == 1 || n_spk_id == B)), "ddsp_unit2ctrl: spk_id must hold 1 or B ids");
     DDSP_REQUIRE(ctx, n_mix == 0 || (mix_ids_host && mix_w_host), "ddsp_unit2ctrl: mix arrays missing");

@@ -81,6 +81,15 @@ class _SynthBase(torch.nn.Module):
         ctx = hipddsp.context_for(f0_frames.device)
         return ctx, ctx.phase_scan(f0_frames, self._hop, self._sr, initial_phase, bool(infer), comb_mode, **want)
 
+    def _empty_result(self, f0_frames, sample_rate_phase=False, shared=False):
+        """The (signal, phase, (harmonic, noise)) tuple of an empty batch (nothing is launched)."""
+        Fr = f0_frames.shape[1]
+        T = Fr * self._hop
+        z = lambda *shape: torch.zeros(*shape, device=f0_frames.device)
+        sig = z(0, T)
+        ph = z(0, T, 1) if sample_rate_phase else z(0, Fr, 1)
+        return sig, ph, ((sig, sig) if shared else (z(0, T), z(0, T)))
+
     def _training_graph(self):
         """True when the call must be recorded for autograd (grad mode on and some parameter wants a gradient)."""
         return torch.is_grad_enabled() and any(p.requires_grad for p in self.unit2ctrl.parameters())
@@ -201,6 +210,8 @@ class CombSub(_SynthBase):
                 infer=True, noise=None, noise_seed=None, **kwargs):
         """units (B,Fr,n_unit), f0 (B,Fr,1) Hz, volume (B,Fr), spk_id (B,1)|(1,1) int64 1-based ->
         (signal (B,T), phase_frames (B,Fr,1), (harmonic (B,T), noise (B,T)))."""
+        if units_frames.shape[0] == 0:
+            return self._empty_result(f0_frames)
         if self._training_graph():
             pf, signal, harmonic, noise_out = _SynthTrainFn.apply(
                 self, units_frames, f0_frames, volume_frames, spk_id, spk_mix_dict, initial_phase, infer, noise,
@@ -276,6 +287,8 @@ class Sins(_SynthBase):
         """Same contract as CombSub.forward except that the returned phase is sample-rate (B,T,1)
         (reference `ddsp/vocoder.py:423`).  `max_upsample_dim` is accepted and ignored: the bank kernel never
         materialises the (B,T,chunk) tensors the reference chunks to bound."""
+        if units_frames.shape[0] == 0:
+            return self._empty_result(f0_frames, sample_rate_phase=True)
         if self._training_graph():
             ph, signal, harmonic, noise_out = _SynthTrainFn.apply(
                 self, units_frames, f0_frames, volume_frames, spk_id, spk_mix_dict, initial_phase, infer, noise,
@@ -324,6 +337,8 @@ class CombSubFast(_SynthBase):
                 infer=True, noise=None, noise_seed=None, **kwargs):
         """Returns (signal, phase_frames (B,Fr,1), (signal, signal)) - the same tensor three times, like the
         reference (`ddsp/vocoder.py:492`)."""
+        if units_frames.shape[0] == 0:
+            return self._empty_result(f0_frames, shared=True)
         if self._training_graph():
             pf, signal = _SynthTrainFn.apply(self, units_frames, f0_frames, volume_frames, spk_id, spk_mix_dict,
                                              initial_phase, infer, noise, noise_seed, *self.unit2ctrl.parameters())

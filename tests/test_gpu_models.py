@@ -175,3 +175,40 @@ def test_sins_bank_stage(ctx, dev):
     want = O.harmonic_bank(amps, phase, HOP)
     got = ctx.sins_bank(ctrl.reshape(B * Fr, -1).to(dev), 4, H, f0f.to(dev), phase.to(dev), B, Fr, HOP, 44100).cpu()
     assert rms(got - want) < 2e-6 and (got - want).abs().max() < 2e-5, rms(got - want)
+
+
+# ---- edge shapes ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["CombSub", "Sins", "CombSubFast"])
+@pytest.mark.parametrize("B,Fr", [(1, 1), (1, 3), (2, 33)])
+def test_tiny_and_ragged_shapes(dev, lib_path, name, B, Fr):
+    model, cfg = synthetic.build_model(name, seed=3)
+    sd = model.state_dict()
+    inp = synthetic.make_inputs(9000 + Fr, B, Fr)
+    with torch.no_grad():
+        want = OS.FORWARD[cfg["type"]](sd, cfg, inp["units"], inp["f0"], inp["volume"], inp["spk_id"], noise=inp["noise"])[0]
+    model = model.to(dev)
+    d = _to(inp, dev)
+    with torch.no_grad():
+        got = model(d["units"], d["f0"], d["volume"], d["spk_id"], noise=d["noise"])[0]
+    assert got.shape == (B, Fr * HOP)
+    assert rms(got.cpu() - want) < GATE, (name, B, Fr, rms(got.cpu() - want))
+
+
+def test_empty_batch_and_wide_units(dev, lib_path):
+    from ddsp.vocoder import CombSubFast
+    model, cfg = synthetic.build_model("CombSubFast", seed=3, device=dev)
+    with torch.no_grad():
+        out, ph, _ = model(torch.zeros(0, 5, 256, device=dev), torch.zeros(0, 5, 1, device=dev),
+                           torch.zeros(0, 5, device=dev), torch.ones(1, 1, dtype=torch.long, device=dev))
+    assert out.shape == (0, 5 * HOP) and ph.shape == (0, 5, 1)
+    # 768-wide units (contentvec768 / hubertbase768 encoders of the reference configs), single speaker
+    torch.manual_seed(4)
+    wide = CombSubFast(44100, 512, n_unit=768, n_spk=1)
+    sd = wide.state_dict()
+    cfg768 = dict(type="CombSubFast", sampling_rate=44100, block_size=512, n_unit=768, n_spk=1)
+    inp = synthetic.make_inputs(77, 2, 20, n_unit=768, n_spk=1)
+    with torch.no_grad():
+        want = OS.combsubfast_forward(sd, cfg768, inp["units"], inp["f0"], inp["volume"], inp["spk_id"], noise=inp["noise"])[0]
+        d = _to(inp, dev)
+        got = wide.to(dev)(d["units"], d["f0"], d["volume"], d["spk_id"], noise=d["noise"])[0]
+    assert rms(got.cpu() - want) < GATE
