@@ -28,7 +28,10 @@ extern "C" int ddsp_gemm_f32(ddsp_ctx* ctx, void* stream, const float* A, int64_
         else if (tile == 13) gemm::launch_dma<128, 128, gemm::EpiStore, 2>(st, g, 1, e);
         else if (tile == 14) gemm::launch_dma<128, 64, gemm::EpiStore, 2>(st, g, 1, e);
         else if (tile == 20) gemm::launch_dma<128, 64, gemm::EpiStore, 3, 1>(st, g, 1, e);   // no MFMA (timing only)
-        else gemm::launch_dma<128, 64, gemm::EpiStore, 3, 2>(st, g, 1, e);                    // no DMA (timing only)
+        else if (tile == 21) gemm::launch_dma<128, 64, gemm::EpiStore, 3, 2>(st, g, 1, e);   // no DMA (timing only)
+        else if (tile == 22) gemm::launch_dma<128, 64, gemm::EpiStore, 3, 6>(st, g, 1, e);   // no DMA, no stores
+        else if (tile == 23) gemm::launch_dma<128, 64, gemm::EpiStore, 3, 10>(st, g, 1, e);  // no DMA, no barrier
+        else gemm::launch_dma<128, 64, gemm::EpiStore, 3, 14>(st, g, 1, e);                   // MFMA + LDS reads only
     } else if (a_k_contig && b_k_contig) {
         TILE(true, true)
     } else if (a_k_contig && !b_k_contig) {

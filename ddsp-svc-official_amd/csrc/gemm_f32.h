@@ -52,6 +52,32 @@ template <class E, class = void>
 struct epi_wants_pair : std::false_type {};
 template <class E>
 struct epi_wants_pair<E, std::void_t<decltype(E::kPair)>> : std::true_type {};
+// An epilogue that offers `vec_ok()` / `store4(z, m, n, f32x4)` gets whole 16-byte row pieces: the accumulator tile
+// is transposed 4x4 across lane quads first, so that one store instruction writes eight 128-byte row segments
+// instead of two (dword stores are issue-bound: tools/gemm_ab.py, 20 us of 95 at N=1536, K=256).
+template <class E, class = void>
+struct epi_has_store4 : std::false_type {};
+template <class E>
+struct epi_has_store4<E, std::void_t<decltype(E::kStore4)>> : std::true_type {};
+
+// 4x4 transpose across the four lanes of a quad: in x[i] = (row i, column q) for lane q; out x[k] = (row q, column k)
+__device__ __forceinline__ void quad_transpose(float (&x)[4], int q) {
+    const bool odd = q & 1, hi = q & 2;
+    auto swap1 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); };
+    auto swap2 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); };
+    // round 1 (lane ^ 1): even lanes end with rows 0 and 2, odd lanes with rows 1 and 3, each for columns (q&~1, q|1)
+    const float r0 = swap1(odd ? x[0] : x[1]);
+    const float r1 = swap1(odd ? x[2] : x[3]);
+    const float a_lo = odd ? r0 : x[0], a_hi = odd ? x[1] : r0;   // row (q&1)
+    const float b_lo = odd ? r1 : x[2], b_hi = odd ? x[3] : r1;   // row 2 + (q&1)
+    // round 2 (lane ^ 2): lanes 0,1 collect columns 2,3 of their low row, lanes 2,3 columns 0,1 of their high row
+    const float s_lo = swap2(hi ? a_lo : b_lo);
+    const float s_hi = swap2(hi ? a_hi : b_hi);
+    x[0] = hi ? s_lo : a_lo;
+    x[1] = hi ? s_hi : a_hi;
+    x[2] = hi ? b_lo : s_lo;
+    x[3] = hi ? b_hi : s_hi;
+}
 
 template <int BM, int BN, bool A_KC, bool B_KC, int A_MODE, class Epi, int NW = 4>
 __global__ void __launch_bounds__(64 * NW) kernel(Args g, Epi epi) {
@@ -290,8 +316,8 @@ __global__ void __launch_bounds__(64 * NW) kernel(Args g, Epi epi) {
 // address), so that the MFMA operand fetch - lane (i = l&31, h = l>>5) reads its 16 k-values 16h..16h+15 of row i
 // as four ds_read_b128 - is bank-conflict-free.  The MFMA k-order is permuted (step s of lane half h is
 // k = 16h + s) identically for A and B, which leaves the sum unchanged.
-template <int BM, int BN, class Epi, int NS = 3, int ABLATE = 0>  // ABLATE (timing experiments only): 1 = no MFMA, 2 = no DMA
-__global__ void __launch_bounds__(512) kernel_dma(Args g, Epi epi, int tiles_m, int tiles_n, int total_tiles) {
+template <int BM, int BN, class Epi, int NS = 3, int ABLATE = 0>  // ABLATE bit mask (timing experiments only): 1 no MFMA, 2 no DMA, 4 no epilogue stores, 8 no barrier
+__global__ void __launch_bounds__(512, (BM * BN <= 128 * 128 ? 4 : 2)) kernel_dma(Args g, Epi epi, int tiles_m, int tiles_n, int total_tiles) {
     constexpr int NW = 8, WGM = 4, WGN = 2;
     constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
     constexpr int ROWS = BM + BN;            // rows per stage
@@ -352,7 +378,7 @@ __global__ void __launch_bounds__(512) kernel_dma(Args g, Epi epi, int tiles_m, 
     if (steps > 0) tile_src((int)blockIdx.x, src_cur);
     auto issue_next = [&]() {
         if (issued >= steps) return;
-        if (ABLATE != 2) issue(src_cur, issue_kt, issued % NS);
+        if (!(ABLATE & 2)) issue(src_cur, issue_kt, issued % NS);
         ++issued;
         if (++issue_kt == nk) {
             issue_kt = 0;
@@ -379,7 +405,7 @@ __global__ void __launch_bounds__(512) kernel_dma(Args g, Epi epi, int tiles_m, 
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // ... and every other wave says the same; the barrier also fences the reads of stage (step+2)%3 (step-1)
-        __builtin_amdgcn_s_barrier();
+        if (!(ABLATE & 8)) __builtin_amdgcn_s_barrier();
         issue_next();  // step + 2
         const float* st = lds + (step % NS) * STAGE;
         f32x4 av[TM][4], bv[TN][4];
@@ -397,7 +423,7 @@ __global__ void __launch_bounds__(512) kernel_dma(Args g, Epi epi, int tiles_m, 
 #pragma unroll
             for (int c = 0; c < 4; ++c) bv[j][c] = *(const f32x4*)(rp + 4 * ((4 * lh + c) ^ ((row >> 1) & 7)));
         }
-        if (ABLATE == 1) {
+        if (ABLATE & 1) {
             // keep the operand reads alive without the matrix pipe
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -419,6 +445,32 @@ __global__ void __launch_bounds__(512) kernel_dma(Args g, Epi epi, int tiles_m, 
             const int per_z = tiles_m * tiles_n;
             const int z = tile / per_z, rem = tile - z * per_z;
             const int m0 = (rem / tiles_n) * BM, n0 = (rem % tiles_n) * BN;
+            bool vec = false;
+            if constexpr (epi_has_store4<Epi>::value) vec = epi.vec_ok() && n0 + BN <= g.N;
+            if (vec) {
+                if constexpr (epi_has_store4<Epi>::value) {
+                    const int q = lane & 3;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const int n = n0 + wn + 32 * j + (lr & ~3);   // first of this lane's four columns
+#pragma unroll
+                            for (int rg = 0; rg < 4; ++rg) {
+                                float x[4] = {acc[i][j][4 * rg], acc[i][j][4 * rg + 1], acc[i][j][4 * rg + 2], acc[i][j][4 * rg + 3]};
+                                quad_transpose(x, q);
+                                const int m = m0 + wm + 32 * i + q + 8 * rg + 4 * lh;
+                                if constexpr ((ABLATE & 4) != 0) {
+                                    if (x[0] == 12345.678f) epi.store4(z, m, n, f32x4{x[0], x[1], x[2], x[3]});
+                                } else {
+                                    if (m < g.M) epi.store4(z, m, n, f32x4{x[0], x[1], x[2], x[3]});
+                                }
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) acc[i][j][4 * rg + r] = 0.f;
+                            }
+                        }
+                }
+            } else
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -432,6 +484,8 @@ __global__ void __launch_bounds__(512) kernel_dma(Args g, Epi epi, int tiles_m, 
                         if constexpr (epi_wants_pair<Epi>::value) {
                             const float other = __shfl_xor(acc[i][j][r], 1, 64);
                             if (n_ok && m < g.M) epi(z, m, n, acc[i][j][r], other);
+                        } else if constexpr ((ABLATE & 4) != 0) {
+                            if (acc[i][j][r] == 12345.678f) epi(z, m, n, acc[i][j][r], cb);
                         } else {
                             if (n_ok && m < g.M) epi(z, m, n, acc[i][j][r], cb);
                         }
@@ -524,6 +578,15 @@ struct EpiStore {  // C = acc (+ bias[n])
         float* c = C + (int64_t)(z / zdiv) * sC_hi + (int64_t)(z % zdiv) * sC_lo;
         c[(int64_t)m * ldc + n] = v + cb;
     }
+    static constexpr bool kStore4 = true;
+    __device__ __forceinline__ bool vec_ok() const {
+        return ((uintptr_t)C % 16) == 0 && ldc % 4 == 0 && sC_hi % 4 == 0 && sC_lo % 4 == 0;
+    }
+    __device__ __forceinline__ void store4(int z, int m, int n, f32x4 v) const {
+        float* c = C + (int64_t)(z / zdiv) * sC_hi + (int64_t)(z % zdiv) * sC_lo;
+        if (bias) v += *(const f32x4_u*)(bias + n);
+        *(f32x4*)(c + (int64_t)m * ldc + n) = v;
+    }
 };
 
 struct EpiResidual {  // C = res + acc + bias[n]   (res may alias C)
@@ -535,6 +598,12 @@ struct EpiResidual {  // C = res + acc + bias[n]   (res may alias C)
     __device__ __forceinline__ void operator()(int, int m, int n, float v, float cb) const {
         const int64_t o = (int64_t)m * ldc + n;
         C[o] = res[o] + (v + cb);
+    }
+    static constexpr bool kStore4 = true;
+    __device__ __forceinline__ bool vec_ok() const { return (((uintptr_t)C | (uintptr_t)res) % 16) == 0 && ldc % 4 == 0; }
+    __device__ __forceinline__ void store4(int, int m, int n, f32x4 v) const {
+        const int64_t o = (int64_t)m * ldc + n;
+        *(f32x4*)(C + o) = *(const f32x4*)(res + o) + (v + *(const f32x4_u*)(bias + n));
     }
 };
 

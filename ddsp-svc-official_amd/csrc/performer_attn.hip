@@ -39,7 +39,7 @@ __device__ __forceinline__ void load_half_row(const float* __restrict__ row, boo
     }
 }
 
-__global__ void __launch_bounds__(64) performer_kv_kernel(const float* __restrict__ k, const float* __restrict__ v,
+__global__ void __launch_bounds__(64, 2) performer_kv_kernel(const float* __restrict__ k, const float* __restrict__ v,
                                                           const float* __restrict__ P, int Fr, float* __restrict__ ctx,
                                                           float* __restrict__ ks) {
     // 1-D grid, XCD-aware: workgroups id and id+8 share an XCD (and its L2), so the NJT feature tiles of one
@@ -113,10 +113,11 @@ __global__ void __launch_bounds__(64) performer_kv_kernel(const float* __restric
     }
 }
 
-__global__ void __launch_bounds__(64) performer_q_kernel(const float* __restrict__ q, const float* __restrict__ P,
-                                                         const float* __restrict__ ctx, const float* __restrict__ ks,
-                                                         int Fr, int n_ft, float* __restrict__ attn) {
+__global__ void __launch_bounds__(64, 2) performer_q_kernel(const float* __restrict__ q, const float* __restrict__ P,
+                                                            const float* __restrict__ ctx, const float* __restrict__ ks,
+                                                            int Fr, int n_ft, float* __restrict__ attn) {
     __shared__ float tile[32 * 65];
+    __shared__ float csum_s[64], dinv_s[32];
     // XCD-aware 1-D grid (see performer_kv_kernel): the frame tiles of one (utterance, head) share ctx / ks
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int ft = slot % n_ft, bh = (slot / n_ft) * 8 + xcd, b = bh / H, h = bh % H;
@@ -129,77 +130,84 @@ __global__ void __launch_bounds__(64) performer_q_kernel(const float* __restrict
     for (int s = 0; s < 32; ++s) ss = fmaf(qb[s], qb[s], ss);
     ss += __shfl_xor(ss, 32, 64);
     const float diag = ss * 0.5f * (DN * DN);
-    f32x16 S[NJT];
-    float pa[32];
-    load_half_row(P + (int64_t)jl * DH + 32 * kh, true, pa);
-#pragma unroll
-    for (int jt = 0; jt < NJT; ++jt) {
-        float pn[32];
-        const int jn = 32 * (jt + 1) + jl;
-        load_half_row(P + (int64_t)jn * DH + 32 * kh, (jt + 1 < NJT) && jn < NF, pn);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) S[jt][r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 32; ++s) S[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s], qb[s], S[jt], 0, 0, 0);
-#pragma unroll
-        for (int s = 0; s < 32; ++s) pa[s] = pn[s];
-    }
-    // row maximum over the 266 real features of this lane's frame
-    float mx = -3.0e38f;
-#pragma unroll
-    for (int jt = 0; jt < NJT; ++jt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (32 * jt + acc_row(r, kh) < NF) mx = fmaxf(mx, DN * S[jt][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float* ksr = ks + (int64_t)bh * LDF;
     const float* cd = ctx + (int64_t)bh * NF * DH + jl;
-    float D = 0.f;
+
+    // The feature tiles are consumed one at a time with a running row maximum (the softmax-kernel stabiliser of
+    // ddsp/pcmer.py:69-77 is the maximum over ALL 266 features): when a tile raises the maximum of a frame, what
+    // that frame has accumulated so far is rescaled by exp(old - new).  The eps term of q' = r*(exp(.) + eps) does
+    // not scale, so it is carried as eps * (column sums of ctx) and eps * sum(ks) and added at the end.  Only one
+    // 32 x 32 tile of projections is alive at a time: 2 waves per SIMD instead of 1 (393 registers before).
+    float m_run = -3.0e38f, Dacc = 0.f, ks_sum = 0.f, cs0 = 0.f, cs1 = 0.f;
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
-    // ctx / ks operands of one feature tile are fetched together (48 loads in flight), one tile ahead of their use,
-    // so the L2 latency is paid once per tile instead of once per accumulator register
-    float a0[16], a1[16], kv[16];
-    auto fetch = [&](int jt, float (&x0)[16], float (&x1)[16], float (&xk)[16]) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int f = 32 * jt + acc_row(r, kh);
-            const bool ok = (jt < NJT) && f < NF;
-            x0[r] = ok ? cd[(int64_t)f * DH] : 0.f;
-            x1[r] = ok ? cd[(int64_t)f * DH + 32] : 0.f;
-            xk[r] = ok ? ksr[f] : 0.f;
-        }
-    };
-    fetch(0, a0, a1, kv);
-#pragma unroll
+    float pa[32];
+    load_half_row(P + (int64_t)jl * DH + 32 * kh, true, pa);
+#pragma unroll 1   // (unrolled, the scheduler hoists every tile's loads to the top and spills)
     for (int jt = 0; jt < NJT; ++jt) {
-        float n0[16], n1[16], nk[16];
-        fetch(jt + 1, n0, n1, nk);
+        // operands of this tile's second product: in flight under the 32 MFMAs of the first
+        float a0[16], a1[16], kv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int f = 32 * jt + acc_row(r, kh);
             const bool ok = f < NF;
-            const float u = ok ? RATIO * (fast_exp((DN * S[jt][r] - diag) - mx) + 1e-4f) : 0.f;
-            D = fmaf(u, kv[r], D);
-            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[r], u, o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], u, o1, 0, 0, 0);
+            a0[r] = ok ? cd[(int64_t)f * DH] : 0.f;
+            a1[r] = ok ? cd[(int64_t)f * DH + 32] : 0.f;
+            kv[r] = ok ? ksr[f] : 0.f;
+        }
+        float pn[32];
+        const int jn = 32 * (jt + 1) + jl;
+        load_half_row(P + (int64_t)jn * DH + 32 * kh, (jt + 1 < NJT) && jn < NF, pn);
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) S = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s], qb[s], S, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 32; ++s) pa[s] = pn[s];
+        float tmax = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (32 * jt + acc_row(r, kh) < NF) tmax = fmaxf(tmax, DN * S[r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float sc = fast_exp(m_run - m_new);
+        m_run = m_new;
+        Dacc *= sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0[r] *= sc;
+            o1[r] *= sc;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            a0[r] = n0[r];
-            a1[r] = n1[r];
-            kv[r] = nk[r];
+            const bool ok = 32 * jt + acc_row(r, kh) < NF;
+            const float u = ok ? fast_exp((DN * S[r] - diag) - m_run) : 0.f;
+            Dacc = fmaf(u, kv[r], Dacc);
+            ks_sum += kv[r];
+            cs0 += a0[r];
+            cs1 += a1[r];
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[r], u, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], u, o1, 0, 0, 0);
         }
     }
-    D += __shfl_xor(D, 32, 64);
-    const float dinv = 1.0f / (D + 1e-8f);
+    Dacc += __shfl_xor(Dacc, 32, 64);
+    ks_sum += __shfl_xor(ks_sum, 32, 64);
+    cs0 += __shfl_xor(cs0, 32, 64);
+    cs1 += __shfl_xor(cs1, 32, 64);
+    const float D = RATIO * fmaf(1e-4f, ks_sum, Dacc);
+    if (kh == 0) {
+        csum_s[jl] = 1e-4f * cs0;
+        csum_s[32 + jl] = 1e-4f * cs1;
+        dinv_s[jl] = RATIO / (D + 1e-8f);
+    }
     // o[r] = out^T[e = acc_row(r,kh) (+32)][frame jl]: transpose through LDS, leave as rows of 64 floats
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int e = acc_row(r, kh);
-        tile[jl * 65 + e] = o0[r] * dinv;
-        tile[jl * 65 + 32 + e] = o1[r] * dinv;
+        tile[jl * 65 + e] = o0[r];
+        tile[jl * 65 + 32 + e] = o1[r];
     }
     __syncthreads();
 #pragma unroll
@@ -208,7 +216,10 @@ __global__ void __launch_bounds__(64) performer_q_kernel(const float* __restrict
         const int row = idx >> 4, c4 = (idx & 15) * 4;
         const int fr = 32 * ft + row;
         if (fr < Fr) {
-            f32x4 o = {tile[row * 65 + c4], tile[row * 65 + c4 + 1], tile[row * 65 + c4 + 2], tile[row * 65 + c4 + 3]};
+            const float di = dinv_s[row];
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (tile[row * 65 + c4 + e] + csum_s[c4 + e]) * di;
             *(f32x4*)(attn + ((int64_t)b * Fr + fr) * INNER + h * DH + c4) = o;
         }
     }

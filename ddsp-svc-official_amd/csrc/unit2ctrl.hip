@@ -55,6 +55,13 @@ struct EpiSplit3 {  // column block n / 512 selects the destination matrix (q, k
     __device__ __forceinline__ void operator()(int, int m, int n, float v, float cb) const {
         out[n >> 9][(int64_t)m * INNER + (n & (INNER - 1))] = v + cb;
     }
+    static constexpr bool kStore4 = true;
+    __device__ __forceinline__ bool vec_ok() const {
+        return (((uintptr_t)out[0] | (uintptr_t)out[1] | (uintptr_t)out[2]) % 16) == 0;
+    }
+    __device__ __forceinline__ void store4(int, int m, int n, f32x4 v) const {
+        *(f32x4*)(out[n >> 9] + (int64_t)m * INNER + (n & (INNER - 1))) = v + *(const gemm::f32x4_u*)(bias + n);
+    }
 };
 
 // W[o][:] = g[o] * v[o][:] / ||v[o]||_2   (old-style weight_norm, ddsp/unit2control.py:61); one wave per row
