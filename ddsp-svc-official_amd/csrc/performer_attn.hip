@@ -4,236 +4,260 @@
 // Replaces, for inference, the chain  [k P^T GEMM -> exp pass -> key sums -> k'^T v GEMM]  and
 // [q P^T GEMM -> max/exp pass -> 1/D pass -> q' ctx GEMM]  of ddsp/pcmer.py:69-77,123-159 (unit2ctrl.hip keeps
 // the unfused chain for training, whose backward needs q' and k').  The 94 MB q'/k' matrices per layer never
-// exist: a 32 x 32 tile of projected values lives in the MFMA accumulator, is exponentiated in place and is fed
-// straight back as the next product's operand (accumulator rows = the index the next product sums over):
-//   K kernel, item (b, h, feature tile jt): for each 32-frame tile:  S = k_tile P_jt^T  (frames x features, lane =
-//     feature), k' = r*exp(dn*S - diag + eps), ks += column sums, ctx_jt (32 features x 64) += k'^T v_tile where
-//     accumulator register r of lane half h IS the A operand of k-step (frame row(r,h)).
-//   Q kernel, item (b, h, frame tile ft): S^T = P q_tile^T for all 9 feature tiles (features x frames, lane = frame),
-//     row max = max over registers (+ one cross-half shuffle), q' in place, D = q'.ks, out^T (64 x 32 frames) +=
-//     ctx^T q' with the accumulator registers as B operands; out / D is transposed through 8 KB of LDS so the
-//     (frame, head) rows leave as 256-byte segments.
-// Operands come straight from L2 into registers with the permuted-k trick (lane half h owns k = 32h..32h+31 of a
-// 64-long row: eight 16-byte loads), so there is no LDS staging and no barrier.  All arithmetic fp32 (MFMA 32x32x2).
+// exist: a 16 x 16 tile of projected values lives in the MFMA accumulator (4 registers), is exponentiated in place
+// and is fed straight back as the next product's operand - accumulator register t of lane group g is the index
+// 4g + t of the dimension the next product sums over, which is exactly the 16x16x4 operand layout (k = lane >> 4)
+// with the four k of step t permuted; the other operand applies the same permutation.
+//   K kernel, item (b, h, 16-feature tile jt): for each 16-frame tile:  S = k_tile P_jt^T (frames x features, lane
+//     column = feature), k' = r*exp(dn*S - diag + eps), ks += column sums, ctx_jt (16 features x 64) += k'^T v_tile.
+//     ctx leaves TRANSPOSED, ctxT[e][j] with row stride 272, so that the Q kernel reads its operand as float4.
+//   Q kernel, item (b, h, 16-frame tile ft): for each feature tile  S^T = P_jt q_tile^T (features x frames, lane
+//     column = frame), running row maximum (see below), q' in place, D += q'.ks, out^T (64 x 16 frames) +=
+//     ctxT_jt q'; the lane then owns 4 consecutive channels of one frame per 16-channel block: float4 stores.
+// 16-wide tiles pad 266 features to 272 and 172 frames to 176 (4.6 % of the MACs; 32-wide tiles: 21 %), need ~100
+// registers (4 waves per SIMD cover the L2 latency and each other's exp / dependent-MFMA bubbles; the 32-wide
+// version sat at 1-2 waves and 43 % MFMA duty), and the first product's operands are read with the permuted-k trick
+// (lane group g owns k = 16g..16g+15 of a 64-long row: four 16-byte loads), so there is no LDS staging and no
+// barrier.  The four waves of a workgroup take four neighbouring tiles of the SAME (utterance, head): they read the
+// same rows at about the same time, so three of the four reads hit the CU's L1.  All arithmetic fp32.
 #include "performer_attn.h"
 
 namespace {
 
-constexpr int H = 8, DH = 64, INNER = 512, NF = 266, LDF = 268, NJT = 9;
+constexpr int H = 8, DH = 64, INNER = 512, NF = 266;
+constexpr int LDJ = PERFORMER_LDJ;             // 272 = 17 feature tiles
+constexpr int NJT = LDJ / 16;                  // 17
+constexpr int KST = PERFORMER_KS_STRIDE;       // per (utterance, head): ks[272] | column-sum parts[17][64] | ks-sum parts[17]
+constexpr int OFF_CPART = LDJ, OFF_KPART = LDJ + NJT * DH;
+constexpr int KV_GROUPS = (NJT + 3) / 4;       // workgroups (4 waves = 4 feature tiles) per (utterance, head)
 constexpr float DN = 0.35355339059327373f;     // 64^-0.25
 constexpr float RATIO = 0.06131393394849658f;  // 266^-0.5
+constexpr float EPS = 1e-4f;
+constexpr float LOG2E = 1.44269504088896341f;
+// Everything inside the exponentials is carried in the base-2 domain (v_exp_f32 IS exp2): the projection operand is
+// pre-scaled by dn*log2(e), and -diag = -0.5*dn^2*|x|^2 enters through ONE extra MFMA step whose k-slot g carries
+// lane group g's partial sum of squares against the constant below - the matrix pipe does the cross-group sum and
+// the broadcast along the tile, no shuffles.  fp32 MFMA and vector ALU instructions do not overlap on this chip
+// (SQ_VALU_MFMA_COEXEC_CYCLES = 0, busy + VALU-active cycles add up to the wave time), so every vector instruction
+// removed from these loops is matrix time won.
+constexpr float PSCALE = DN * LOG2E;
+constexpr float NEG_HALF = -0.5f * DN * DN * LOG2E;
+constexpr float KOFF = EPS * LOG2E - 4.0276409f;   // eps (inside the key exponential) and log2(266^-0.5)
+constexpr float MASKED = -1000.f;                  // exp2 -> 0: pad features / frames are switched off in the C init
 
-__device__ __forceinline__ int acc_row(int r, int kh) { return (r & 3) + 8 * (r >> 2) + 4 * kh; }
-// exp through the hardware exp2 (v_exp_f32, ~1 ulp): 2 instructions instead of ~15; relative error ~1e-7*|x|, far
-// inside the tolerance of the positive random features (their arguments are O(10))
-__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-// 32 consecutive floats of a 64-float row (the half this lane owns), zero when the row is out of range
-__device__ __forceinline__ void load_half_row(const float* __restrict__ row, bool valid, float (&dst)[32]) {
+// 16 consecutive floats of a 64-float row (the quarter this lane group owns)
+__device__ __forceinline__ void load_quarter_row(const float* __restrict__ row, float (&dst)[16]) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (valid) v = *(const f32x4*)(row + 4 * c);
+    for (int c = 0; c < 4; ++c) {
+        const f32x4_t v = *(const f32x4_t*)(row + 4 * c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) dst[4 * c + e] = v[e];
     }
 }
 
-__global__ void __launch_bounds__(64, 2) performer_kv_kernel(const float* __restrict__ k, const float* __restrict__ v,
-                                                          const float* __restrict__ P, int Fr, float* __restrict__ ctx,
-                                                          float* __restrict__ ks) {
-    // 1-D grid, XCD-aware: workgroups id and id+8 share an XCD (and its L2), so the NJT feature tiles of one
-    // (utterance, head) - which all re-read the same k and v rows - are dealt to ONE XCD group (id & 7)
+// sum / max over the four lane groups (lanes c, c+16, c+32, c+48)
+__device__ __forceinline__ float group_sum(float x) {
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    return x;
+}
+__device__ __forceinline__ float group_max(float x) {
+    x = fmaxf(x, __shfl_xor(x, 16, 64));
+    x = fmaxf(x, __shfl_xor(x, 32, 64));
+    return x;
+}
+
+__global__ void __launch_bounds__(256, 4) performer_kv_kernel(const float* __restrict__ k, const float* __restrict__ v,
+                                                              const float* __restrict__ P, int Fr,
+                                                              float* __restrict__ ctxT, float* __restrict__ ks) {
+    // 1-D grid, XCD-aware: workgroups id and id+8 share an XCD (and its L2), so all feature tiles of one
+    // (utterance, head) - which re-read the same k and v rows - are dealt to ONE XCD (id & 7)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int jt = slot % NJT, bh = (slot / NJT) * 8 + xcd, b = bh / H, h = bh % H;
-    const int lane = threadIdx.x, jl = lane & 31, kh = lane >> 5;
-    const int j = 32 * jt + jl;
-    float pb[32];
-    load_half_row(P + (int64_t)j * DH + 32 * kh, j < NF, pb);
-    f32x16 c0, c1;
+    const int grp = slot % KV_GROUPS, bh = (slot / KV_GROUPS) * 8 + xcd, b = bh / H, h = bh % H;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int jt = 4 * grp + wave;
+    if (jt >= NJT) return;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int j = 16 * jt + c;                  // this lane's feature (column of S, row of ctx)
+    // out-of-range rows are CLAMPED (finite garbage), and switched off through the accumulator's initial value
+    float pb[16];
+    load_quarter_row(P + (int64_t)(j < NF ? j : NF - 1) * DH + 16 * g, pb);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.f;
-    float ksum = 0.f;
-    const int n_ft = (Fr + 31) / 32;
-    const float* kb = k + ((int64_t)b * Fr) * INNER + h * DH + 32 * kh;
-    const float* vb = v + ((int64_t)b * Fr) * INNER + h * DH + jl;
-    // lane-constant byte offsets of the 16 frames this lane half feeds to the second product
-    int voff[16];
+    for (int s = 0; s < 16; ++s) pb[s] *= PSCALE;
+    const int n_ft = (Fr + 15) / 16;
+    f32x4_t c_full, c_last;                      // C init of a full frame tile / of the last (ragged) one
 #pragma unroll
-    for (int r = 0; r < 16; ++r) voff[r] = acc_row(r, kh) * INNER;
-    // one frame tile: `cur` holds its k rows, `nxt` receives the next tile's (register ping-pong, no copies)
-    auto tile = [&](int ft, float (&cur)[32], float (&nxt)[32]) {
-        float v0[16], v1[16];
-        const float* vt = vb + (int64_t)(32 * ft) * INNER;
+    for (int r = 0; r < 4; ++r) {
+        c_full[r] = j < NF ? KOFF : MASKED;
+        c_last[r] = (j < NF && 16 * (n_ft - 1) + 4 * g + r < Fr) ? KOFF : MASKED;
+    }
+    f32x4_t acc[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool ok = 32 * ft + acc_row(r, kh) < Fr;
-            v0[r] = ok ? vt[voff[r]] : 0.f;
-            v1[r] = ok ? vt[voff[r] + 32] : 0.f;
+    for (int et = 0; et < 4; ++et) acc[et] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    f32x4_t ksum4 = {0.f, 0.f, 0.f, 0.f};
+    const float* kb = k + ((int64_t)b * Fr) * INNER + h * DH;     // wave-uniform bases, 32-bit lane offsets
+    const float* vb = v + ((int64_t)b * Fr) * INNER + h * DH;
+    const int last = Fr - 1;
+    float ka[16];
+    load_quarter_row(kb + (c < Fr ? c : last) * INNER + 16 * g, ka);
+#pragma unroll 2
+    for (int ft = 0; ft < n_ft; ++ft) {
+        // v operand of the second product: frames 4g+t (t = k-step), channels 16et + c
+        float vv[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int f = 16 * ft + 4 * g + t;
+            f = f < Fr ? f : last;
+#pragma unroll
+            for (int et = 0; et < 4; ++et) vv[et][t] = vb[f * INNER + 16 * et + c];
         }
+        // next tile's k rows (used only after this tile's products)
+        float kn[16];
+        int nf = 16 * (ft + 1) + c;
+        nf = nf < Fr ? nf : last;
+        load_quarter_row(kb + nf * INNER + 16 * g, kn);
         float ss = 0.f;
 #pragma unroll
-        for (int s = 0; s < 32; ++s) ss = fmaf(cur[s], cur[s], ss);
-        ss += __shfl_xor(ss, 32, 64);
-        const float diag = ss * 0.5f * (DN * DN);   // of frame 32*ft + jl, known to lanes jl and jl+32
-        f32x16 S;
+        for (int s = 0; s < 16; ++s) ss = fmaf(ka[s], ka[s], ss);
+        f32x4_t S = ft == n_ft - 1 ? c_last : c_full;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+        for (int s = 0; s < 16; ++s) S = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[s], pb[s], S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_16x16x4f32(ss, NEG_HALF, S, 0, 0, 0);
+        f32x4_t kf;
 #pragma unroll
-        for (int s = 0; s < 32; ++s) S = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[s], pb[s], S, 0, 0, 0);
-        const int nf = 32 * (ft + 1) + jl;
-        load_half_row(kb + (int64_t)nf * INNER, (ft + 1 < n_ft) && nf < Fr, nxt);
+        for (int r = 0; r < 4; ++r) kf[r] = __builtin_amdgcn_exp2f(S[r]);   // row 4g+r = frame within the tile
+        ksum4 += kf;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = acc_row(r, kh);
-            const float dg = __shfl(diag, row, 64);
-            const bool ok = (32 * ft + row < Fr) && (j < NF);
-            const float kf = ok ? RATIO * fast_exp((DN * S[r] - dg) + 1e-4f) : 0.f;
-            ksum += kf;
-            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf, v0[r], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf, v1[r], c1, 0, 0, 0);
-        }
-    };
-    float ka[32], kc[32];
-    load_half_row(kb + (int64_t)jl * INNER, jl < Fr, ka);
-    for (int ft = 0; ft < n_ft; ft += 2) {
-        tile(ft, ka, kc);
-        if (ft + 1 < n_ft) tile(ft + 1, kc, ka);
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int et = 0; et < 4; ++et)
+                acc[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t], vv[et][t], acc[et], 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) ka[s] = kn[s];
     }
-    ksum += __shfl_xor(ksum, 32, 64);
-    if (kh == 0 && j < LDF) ks[(int64_t)bh * LDF + j] = (j < NF) ? ksum : 0.f;
-    float* cd = ctx + (int64_t)bh * NF * DH;
+    float* kr = ks + (int64_t)bh * KST;
+    const float ksum = group_sum((ksum4[0] + ksum4[1]) + (ksum4[2] + ksum4[3]));
+    if (g == 0) kr[j] = ksum;                                    // pad features 266..271 are exact zeros
+    float ktot = ksum;                                           // sum over this tile's 16 features (lanes c)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int f = 32 * jt + acc_row(r, kh);
-        if (f < NF) {
-            cd[(int64_t)f * DH + jl] = c0[r];
-            cd[(int64_t)f * DH + 32 + jl] = c1[r];
-        }
+    for (int m = 1; m < 16; m <<= 1) ktot += __shfl_xor(ktot, m, 64);
+    if (lane == 0) kr[OFF_KPART + jt] = ktot;
+    // acc[et][r] = ctx[feature 16jt + 4g + r][channel 16et + c]  ->  ctxT[channel][feature], 4 features per store
+    float* cd = ctxT + (int64_t)bh * DH * LDJ + 16 * jt + 4 * g;
+#pragma unroll
+    for (int et = 0; et < 4; ++et) {
+        *(f32x4_t*)(cd + (int64_t)(16 * et + c) * LDJ) = acc[et];
+        // this tile's share of the column sums of ctx (the Q kernel's eps term)
+        const float part = group_sum((acc[et][0] + acc[et][1]) + (acc[et][2] + acc[et][3]));
+        if (g == 0) kr[OFF_CPART + jt * DH + 16 * et + c] = part;
     }
 }
 
-__global__ void __launch_bounds__(64, 2) performer_q_kernel(const float* __restrict__ q, const float* __restrict__ P,
-                                                            const float* __restrict__ ctx, const float* __restrict__ ks,
-                                                            int Fr, int n_ft, float* __restrict__ attn) {
-    __shared__ float tile[32 * 65];
-    __shared__ float csum_s[64], dinv_s[32];
-    // XCD-aware 1-D grid (see performer_kv_kernel): the frame tiles of one (utterance, head) share ctx / ks
+__global__ void __launch_bounds__(256, 4) performer_q_kernel(const float* __restrict__ q, const float* __restrict__ P,
+                                                             const float* __restrict__ ctxT, const float* __restrict__ ks,
+                                                             int Fr, int n_grp, float* __restrict__ attn) {
+    // XCD-aware 1-D grid (see performer_kv_kernel): the frame tiles of one (utterance, head) share ctx / ks / P
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int ft = slot % n_ft, bh = (slot / n_ft) * 8 + xcd, b = bh / H, h = bh % H;
-    const int lane = threadIdx.x, jl = lane & 31, kh = lane >> 5;
-    const int frame = 32 * ft + jl;
-    float qb[32];
-    load_half_row(q + ((int64_t)b * Fr + frame) * INNER + h * DH + 32 * kh, frame < Fr, qb);
+    const int grp = slot % n_grp, bh = (slot / n_grp) * 8 + xcd, b = bh / H, h = bh % H;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ft = 4 * grp + wave;
+    if (16 * ft >= Fr) return;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int frame = 16 * ft + c;              // this lane's frame (column of S^T and of out^T)
+    float qb[16];
+    load_quarter_row(q + ((int64_t)b * Fr + (frame < Fr ? frame : Fr - 1)) * INNER + h * DH + 16 * g, qb);
     float ss = 0.f;
 #pragma unroll
-    for (int s = 0; s < 32; ++s) ss = fmaf(qb[s], qb[s], ss);
-    ss += __shfl_xor(ss, 32, 64);
-    const float diag = ss * 0.5f * (DN * DN);
-    const float* ksr = ks + (int64_t)bh * LDF;
-    const float* cd = ctx + (int64_t)bh * NF * DH + jl;
+    for (int s = 0; s < 16; ++s) ss = fmaf(qb[s], qb[s], ss);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) qb[s] *= PSCALE;
+    // (the row maximum runs over the projections WITHOUT the diagonal term, ddsp/pcmer.py:73: diag stays a separate
+    // per-frame constant of the exponent, it does not cancel against the maximum)
+    const float diag2 = -NEG_HALF * group_sum(ss);
+    const float* kr = ks + (int64_t)bh * KST;
+    const float* cd = ctxT + (int64_t)bh * DH * LDJ;
+    const int coff = c * LDJ + 4 * g;
+    // eps terms: column sums of ctx (lane = channel) and sum of ks, from the parts the K kernel left per feature tile
+    float cs_lane = 0.f, ks_tot = lane < NJT ? kr[OFF_KPART + lane] : 0.f;
+#pragma unroll
+    for (int t = 0; t < NJT; ++t) cs_lane += kr[OFF_CPART + t * DH + lane];
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) ks_tot += __shfl_xor(ks_tot, m, 64);
 
     // The feature tiles are consumed one at a time with a running row maximum (the softmax-kernel stabiliser of
     // ddsp/pcmer.py:69-77 is the maximum over ALL 266 features): when a tile raises the maximum of a frame, what
     // that frame has accumulated so far is rescaled by exp(old - new).  The eps term of q' = r*(exp(.) + eps) does
-    // not scale, so it is carried as eps * (column sums of ctx) and eps * sum(ks) and added at the end.  Only one
-    // 32 x 32 tile of projections is alive at a time: 2 waves per SIMD instead of 1 (393 registers before).
-    float m_run = -3.0e38f, Dacc = 0.f, ks_sum = 0.f, cs0 = 0.f, cs1 = 0.f;
-    f32x16 o0, o1;
+    // not scale, so it is carried as eps * (column sums of ctx) and eps * sum(ks) and added at the end.
+    float m_run = -3.0e38f;
+    f32x4_t Dacc = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t o[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
-    float pa[32];
-    load_half_row(P + (int64_t)jl * DH + 32 * kh, true, pa);
-#pragma unroll 1   // (unrolled, the scheduler hoists every tile's loads to the top and spills)
+    for (int et = 0; et < 4; ++et) o[et] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    f32x4_t c_last;                              // C init of the last feature tile: features 266..271 switched off
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c_last[r] = 16 * (NJT - 1) + 4 * g + r < NF ? 0.f : MASKED;
+    float pa[16];
+    load_quarter_row(P + c * DH + 16 * g, pa);
+#pragma unroll 2
     for (int jt = 0; jt < NJT; ++jt) {
-        // operands of this tile's second product: in flight under the 32 MFMAs of the first
-        float a0[16], a1[16], kv[16];
+        // operands of this tile's second product (features 16jt + 4g + t): in flight under the first product
+        f32x4_t ca[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int f = 32 * jt + acc_row(r, kh);
-            const bool ok = f < NF;
-            a0[r] = ok ? cd[(int64_t)f * DH] : 0.f;
-            a1[r] = ok ? cd[(int64_t)f * DH + 32] : 0.f;
-            kv[r] = ok ? ksr[f] : 0.f;
-        }
-        float pn[32];
-        const int jn = 32 * (jt + 1) + jl;
-        load_half_row(P + (int64_t)jn * DH + 32 * kh, (jt + 1 < NJT) && jn < NF, pn);
-        f32x16 S;
+        for (int et = 0; et < 4; ++et) ca[et] = *(const f32x4_t*)(cd + 16 * jt + (coff + 16 * et * LDJ));
+        const f32x4_t kv = *(const f32x4_t*)(kr + 16 * jt + 4 * g);
+        float pn[16];
+        int jn = 16 * (jt + 1) + c;
+        jn = jn < NF ? jn : NF - 1;
+        load_quarter_row(P + jn * DH + 16 * g, pn);
+        f32x4_t S = jt == NJT - 1 ? c_last : f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) S[r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 32; ++s) S = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s], qb[s], S, 0, 0, 0);
-#pragma unroll
-        for (int s = 0; s < 32; ++s) pa[s] = pn[s];
-        float tmax = -3.0e38f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (32 * jt + acc_row(r, kh) < NF) tmax = fmaxf(tmax, DN * S[r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        for (int s = 0; s < 16; ++s) S = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s], qb[s], S, 0, 0, 0);
+        const float tmax = group_max(fmaxf(fmaxf(S[0], S[1]), fmaxf(S[2], S[3])));
         const float m_new = fmaxf(m_run, tmax);
-        const float sc = fast_exp(m_run - m_new);
+        const float sc = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
+        const float dm = m_run + diag2;
         Dacc *= sc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            o0[r] *= sc;
-            o1[r] *= sc;
-        }
+        for (int et = 0; et < 4; ++et) o[et] *= sc;
+        f32x4_t u;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool ok = 32 * jt + acc_row(r, kh) < NF;
-            const float u = ok ? fast_exp((DN * S[r] - diag) - m_run) : 0.f;
-            Dacc = fmaf(u, kv[r], Dacc);
-            ks_sum += kv[r];
-            cs0 += a0[r];
-            cs1 += a1[r];
-            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[r], u, o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], u, o1, 0, 0, 0);
-        }
+        for (int r = 0; r < 4; ++r) u[r] = __builtin_amdgcn_exp2f(S[r] - dm);
+        Dacc += u * kv;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int et = 0; et < 4; ++et)
+                o[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[et][t], u[t], o[et], 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) pa[s] = pn[s];
     }
-    Dacc += __shfl_xor(Dacc, 32, 64);
-    ks_sum += __shfl_xor(ks_sum, 32, 64);
-    cs0 += __shfl_xor(cs0, 32, 64);
-    cs1 += __shfl_xor(cs1, 32, 64);
-    const float D = RATIO * fmaf(1e-4f, ks_sum, Dacc);
-    if (kh == 0) {
-        csum_s[jl] = 1e-4f * cs0;
-        csum_s[32 + jl] = 1e-4f * cs1;
-        dinv_s[jl] = RATIO / (D + 1e-8f);
-    }
-    // o[r] = out^T[e = acc_row(r,kh) (+32)][frame jl]: transpose through LDS, leave as rows of 64 floats
+    const float Dsum = group_sum((Dacc[0] + Dacc[1]) + (Dacc[2] + Dacc[3]));
+    const float D = RATIO * fmaf(EPS, ks_tot, Dsum);
+    const float dinv = RATIO / (D + 1e-8f);
+    // o[et][r] = out^T[channel 16et + 4g + r][frame c]
+    float* orow = attn + ((int64_t)b * Fr + frame) * INNER + h * DH + 4 * g;
+    const float cs_eps = EPS * cs_lane;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int e = acc_row(r, kh);
-        tile[jl * 65 + e] = o0[r];
-        tile[jl * 65 + 32 + e] = o1[r];
-    }
-    __syncthreads();
+    for (int et = 0; et < 4; ++et) {
+        f32x4_t res;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int idx = lane + 64 * i;   // 512 float4 = 32 rows x 16
-        const int row = idx >> 4, c4 = (idx & 15) * 4;
-        const int fr = 32 * ft + row;
-        if (fr < Fr) {
-            const float di = dinv_s[row];
-            f32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (tile[row * 65 + c4 + e] + csum_s[c4 + e]) * di;
-            *(f32x4*)(attn + ((int64_t)b * Fr + fr) * INNER + h * DH + c4) = o;
-        }
+        for (int r = 0; r < 4; ++r) res[r] = (o[et][r] + __shfl(cs_eps, 16 * et + 4 * g + r, 64)) * dinv;
+        if (frame < Fr) *(f32x4_t*)(orow + 16 * et) = res;
     }
 }
 
 }  // namespace
 
-void performer_kv(hipStream_t st, const float* k, const float* v, const float* P, int B, int Fr, float* ctx, float* ks) {
-    // B*H is a multiple of 8, so the XCD-aware decode of the 1-D grid covers every (head, tile) exactly once
-    hipLaunchKernelGGL(performer_kv_kernel, dim3((unsigned)(NJT * B * H)), dim3(64), 0, st, k, v, P, Fr, ctx, ks);
+void performer_kv(hipStream_t st, const float* k, const float* v, const float* P, int B, int Fr, float* ctxT, float* ks) {
+    // B*H is a multiple of 8, so the XCD-aware decode of the 1-D grid covers every (head, tile group) exactly once
+    hipLaunchKernelGGL(performer_kv_kernel, dim3((unsigned)(KV_GROUPS * B * H)), dim3(256), 0, st, k, v, P, Fr, ctxT, ks);
 }
 
-void performer_q(hipStream_t st, const float* q, const float* P, const float* ctx, const float* ks, int B, int Fr,
+void performer_q(hipStream_t st, const float* q, const float* P, const float* ctxT, const float* ks, int B, int Fr,
                  float* attn) {
-    const int n_ft = (Fr + 31) / 32;
-    hipLaunchKernelGGL(performer_q_kernel, dim3((unsigned)(n_ft * B * H)), dim3(64), 0, st, q, P, ctx, ks, Fr, n_ft, attn);
+    const int n_grp = ((Fr + 15) / 16 + 3) / 4;
+    hipLaunchKernelGGL(performer_q_kernel, dim3((unsigned)(n_grp * B * H)), dim3(256), 0, st, q, P, ctxT, ks, Fr, n_grp, attn);
 }

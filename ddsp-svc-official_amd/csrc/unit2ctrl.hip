@@ -783,8 +783,8 @@ static void plan_forward(Arena& a, U2CBufs& bf, const ddsp_u2c_weights& w, int64
         L.v = a.get(M * INNER);
         L.qf = a.get(M8 * LDF);
         L.kf = a.get(M8 * LDF);
-        L.ks = a.get((size_t)B * H * LDF);
-        L.cx = a.get((size_t)B * H * NF * DH);
+        L.ks = a.get((size_t)B * H * PERFORMER_KS_STRIDE);           // (the fused inference kernels pad features to 272)
+        L.cx = a.get((size_t)B * H * PERFORMER_LDJ * DH);
         L.dinv = a.get(M8);
         L.attn = a.get(M * INNER);
         L.g1 = a.get(M * 2 * INNER);
