@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(512, (BM * BN <= 128 * 128 ? 4 : 2)) kernel_dm
     static_assert(PIECES % NW == 0, "stage must split evenly over the waves");
     __shared__ __attribute__((aligned(1024))) float lds[NS * STAGE];   // NS-stage ring (NS-1 tiles in flight)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR
     const int wm = (wave >> 1) * (BM / WGM), wn = (wave & 1) * (BN / WGN);
     const int lr = lane & 31, lh = lane >> 5;
     const int nk = g.K / 32;

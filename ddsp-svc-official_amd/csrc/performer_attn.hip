@@ -9,7 +9,8 @@
 // 4g + t of the dimension the next product sums over, which is exactly the 16x16x4 operand layout (k = lane >> 4)
 // with the four k of step t permuted; the other operand applies the same permutation.
 //   K kernel, item (b, h, 16-feature tile jt): for each 16-frame tile:  S = k_tile P_jt^T (frames x features, lane
-//     column = feature), k' = r*exp(dn*S - diag + eps), ks += column sums, ctx_jt (16 features x 64) += k'^T v_tile.
+//     column = feature), k' = r*exp(dn*S - diag + eps), ks += column sums, ctx_jt (16 features x 64) += k'^T v_tile
+//     (output block et of a lane = channel 4c + et, so v is read as one float4 per frame).
 //     ctx leaves TRANSPOSED, ctxT[e][j] with row stride 272, so that the Q kernel reads its operand as float4.
 //   Q kernel, item (b, h, 16-frame tile ft): for each feature tile  S^T = P_jt q_tile^T (features x frames, lane
 //     column = frame), running row maximum (see below), q' in place, D += q'.ks, out^T (64 x 16 frames) +=
@@ -104,14 +105,14 @@ __global__ void __launch_bounds__(256, 4) performer_kv_kernel(const float* __res
     load_quarter_row(kb + (c < Fr ? c : last) * INNER + 16 * g, ka);
 #pragma unroll 2
     for (int ft = 0; ft < n_ft; ++ft) {
-        // v operand of the second product: frames 4g+t (t = k-step), channels 16et + c
-        float vv[4][4];
+        // v operand of the second product: frames 4g+t (t = k-step); output block et covers channels 4c + et, so
+        // that the four blocks of a lane are ONE 16-byte load per frame
+        f32x4_t vv[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             int f = 16 * ft + 4 * g + t;
             f = f < Fr ? f : last;
-#pragma unroll
-            for (int et = 0; et < 4; ++et) vv[et][t] = vb[f * INNER + 16 * et + c];
+            vv[t] = *(const f32x4_t*)(vb + f * INNER + 4 * c);
         }
         // next tile's k rows (used only after this tile's products)
         float kn[16];
@@ -133,7 +134,7 @@ __global__ void __launch_bounds__(256, 4) performer_kv_kernel(const float* __res
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int et = 0; et < 4; ++et)
-                acc[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t], vv[et][t], acc[et], 0, 0, 0);
+                acc[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t], vv[t][et], acc[et], 0, 0, 0);
 #pragma unroll
         for (int s = 0; s < 16; ++s) ka[s] = kn[s];
     }
@@ -144,14 +145,14 @@ __global__ void __launch_bounds__(256, 4) performer_kv_kernel(const float* __res
 #pragma unroll
     for (int m = 1; m < 16; m <<= 1) ktot += __shfl_xor(ktot, m, 64);
     if (lane == 0) kr[OFF_KPART + jt] = ktot;
-    // acc[et][r] = ctx[feature 16jt + 4g + r][channel 16et + c]  ->  ctxT[channel][feature], 4 features per store
+    // acc[et][r] = ctx[feature 16jt + 4g + r][channel 4c + et]  ->  ctxT[channel][feature], 4 features per store
     float* cd = ctxT + (int64_t)bh * DH * LDJ + 16 * jt + 4 * g;
 #pragma unroll
     for (int et = 0; et < 4; ++et) {
-        *(f32x4_t*)(cd + (int64_t)(16 * et + c) * LDJ) = acc[et];
+        *(f32x4_t*)(cd + (int64_t)(4 * c + et) * LDJ) = acc[et];
         // this tile's share of the column sums of ctx (the Q kernel's eps term)
         const float part = group_sum((acc[et][0] + acc[et][1]) + (acc[et][2] + acc[et][3]));
-        if (g == 0) kr[OFF_CPART + jt * DH + 16 * et + c] = part;
+        if (g == 0) kr[OFF_CPART + jt * DH + 4 * c + et] = part;
     }
 }
 
