@@ -60,6 +60,15 @@ struct epi_has_store4 : std::false_type {};
 template <class E>
 struct epi_has_store4<E, std::void_t<decltype(E::kStore4)>> : std::true_type {};
 
+// An epilogue that declares `kGatedPair` (DMA kernel, 128-wide tiles only: each wave owns two 32-column blocks) gets
+// the two blocks of a wave as (value, gate): B rows are packed so that packed columns 64t..64t+31 are the values and
+// 64t+32..64t+63 the gates of output channels 32t..32t+31.  Both then sit in the same lane and register, the gated
+// product is formed in place and only HALF the columns are stored: out[m][32t + c] = (a + bias_a) * sigmoid(g + bias_g).
+template <class E, class = void>
+struct epi_is_gated : std::false_type {};
+template <class E>
+struct epi_is_gated<E, std::void_t<decltype(E::kGatedPair)>> : std::true_type {};
+
 // 4x4 transpose across the four lanes of a quad: in x[i] = (row i, column q) for lane q; out x[k] = (row q, column k)
 __device__ __forceinline__ void quad_transpose(float (&x)[4], int q) {
     const bool odd = q & 1, hi = q & 2;
@@ -447,7 +456,30 @@ __global__ void __launch_bounds__(512, (BM * BN <= 128 * 128 ? 4 : 2)) kernel_dm
             const int m0 = (rem / tiles_n) * BM, n0 = (rem % tiles_n) * BN;
             bool vec = false;
             if constexpr (epi_has_store4<Epi>::value) vec = epi.vec_ok() && n0 + BN <= g.N;
-            if (vec) {
+            if constexpr (epi_is_gated<Epi>::value) {
+                static_assert(TN == 2, "gated-pair epilogue needs the wave's two column blocks");
+                // (the launcher has checked N % BN == 0 and the output alignment)
+                const int q = lane & 3;
+                const int na = n0 + wn + lr;                       // packed column of this lane's value; gate at +32
+                const float ba = epi.col(na), bg = epi.col(na + 32);
+                const int oc = ((n0 + wn) >> 1) + (lr & ~3);       // first of the lane's four output channels
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        float x[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float a = acc[i][0][4 * rg + r] + ba, gt = acc[i][1][4 * rg + r] + bg;
+                            x[r] = a * (1.0f / (1.0f + expf(-gt)));
+                            acc[i][0][4 * rg + r] = 0.f;
+                            acc[i][1][4 * rg + r] = 0.f;
+                        }
+                        quad_transpose(x, q);
+                        const int m = m0 + wm + 32 * i + q + 8 * rg + 4 * lh;
+                        if (m < g.M) epi.store4(z, m, oc, f32x4{x[0], x[1], x[2], x[3]});
+                    }
+            } else if (vec) {
                 if constexpr (epi_has_store4<Epi>::value) {
                     const int q = lane & 3;
 #pragma unroll

@@ -48,6 +48,35 @@ __global__ void __launch_bounds__(256) pack_qkv_kernel(const float* __restrict__
     }
 }
 
+// pw1 (1024 x 256, rows 0..511 values, 512..1023 gates of the GLU, ddsp/pcmer.py conformer conv module) re-ordered
+// for the gated-pair GEMM epilogue: packed rows 64t..64t+31 = values, 64t+32..64t+63 = gates of channels 32t..32t+31.
+struct GluPackArgs {
+    const float* w[3];
+    const float* b[3];
+};
+__global__ void __launch_bounds__(256) pack_glu_kernel(GluPackArgs a, float* __restrict__ wp, float* __restrict__ bp) {
+    const int l = blockIdx.y;
+    const float* w = a.w[l];
+    const float* bias = a.b[l];
+    float* wo = wp + (size_t)l * 2 * INNER * D;
+    float* bo = bp + (size_t)l * 2 * INNER;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * INNER * (D / 4); i += gridDim.x * blockDim.x) {
+        const int p = i / (D / 4), k4 = (i % (D / 4)) * 4;
+        const int t = p >> 6, within = p & 63;
+        const int src = within < 32 ? 32 * t + within : INNER + 32 * t + (within - 32);
+        *(f32x4*)(wo + (size_t)p * D + k4) = *(const f32x4*)(w + (size_t)src * D + k4);
+        if (k4 == 0) bo[p] = bias[src];
+    }
+}
+
+struct EpiGlu {  // out[m][c] = (a + bias_a) * sigmoid(g + bias_g), formed inside the GEMM (see gemm_f32.h kGatedPair)
+    static constexpr bool kGatedPair = true;
+    float* out;          // (rows, 512)
+    const float* bias;   // packed like the weight rows
+    __device__ __forceinline__ float col(int n) const { return bias[n]; }
+    __device__ __forceinline__ void store4(int, int m, int n, f32x4 v) const { *(f32x4*)(out + (int64_t)m * INNER + n) = v; }
+};
+
 struct EpiSplit3 {  // column block n / 512 selects the destination matrix (q, k or v), each (rows, 512)
     float* out[3];
     const float* bias;
@@ -742,7 +771,7 @@ struct LayerBufs {
     float *x_in, *y, *q, *k, *v, *qf, *kf, *ks, *cx, *dinv, *attn, *x_mid, *y2, *g1, *glu, *pre, *dwo, *x_out;
 };
 struct U2CBufs {
-    float *w1, *w2, *wh, *wqkv, *bqkv, *t1, *t2, *gst, *y_final;
+    float *w1, *w2, *wh, *wqkv, *bqkv, *wglu, *bglu, *t1, *t2, *gst, *y_final;
     LayerBufs l[3];
 };
 
@@ -771,6 +800,8 @@ static void plan_forward(Arena& a, U2CBufs& bf, const ddsp_u2c_weights& w, int64
     bf.wh = a.get((size_t)w.n_out * D);
     bf.wqkv = a.get((size_t)3 * 3 * INNER * D);
     bf.bqkv = a.get((size_t)3 * 3 * INNER);
+    bf.wglu = a.get((size_t)3 * 2 * INNER * D);    // pw1 re-ordered for the fused GLU epilogue (inference)
+    bf.bglu = a.get((size_t)3 * 2 * INNER);
     bf.t1 = a.get(M * D);
     bf.t2 = a.get(M * D);
     bf.gst = a.get((size_t)B * 4 * 2);
@@ -836,6 +867,21 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
              hipLaunchKernelGGL(pack_qkv_kernel, dim3(512), dim3(256), 0, st, w.layer[l].q_w, w.layer[l].k_w, w.layer[l].v_w,
                                 w.layer[l].q_b, w.layer[l].k_b, w.layer[l].v_b, bf.wqkv + (size_t)l * 3 * INNER * D,
                                 bf.bqkv + (size_t)l * 3 * INNER));
+    // Inference, and enough rows that the Linear layers run the 128x128 DMA tile anyway: GLU is formed inside the pw1
+    // GEMM (half the store, no glu kernel).  Training keeps pw1's raw output for the backward pass; small batches keep
+    // the tile shapes that suit them and the separate glu kernel.
+    bool fuse_glu = !bf.l[0].pre && (int64_t)((M + 127) / 128) * (2 * INNER / 128) >= 512;
+    for (int l = 0; l < 3; ++l)
+        fuse_glu = fuse_glu && ((uintptr_t)w.layer[l].cm_pw1_w % 16) == 0;
+    if (fuse_glu) {
+        GluPackArgs ga;
+        for (int l = 0; l < 3; ++l) {
+            ga.w[l] = w.layer[l].cm_pw1_w;
+            ga.b[l] = w.layer[l].cm_pw1_b;
+        }
+        PROF(PF_U2C_PREP, 0, 8.0 * 3 * 2 * INNER * D,
+             hipLaunchKernelGGL(pack_glu_kernel, dim3(128, 3), dim3(256), 0, st, ga, bf.wglu, bf.bglu));
+    }
     // ---- prenet: conv k3 -> GroupNorm(4) -> LeakyReLU -> conv k3 ----
     {
         gemm::Args g = gemm::make(in.units, w.n_unit, bf.w1, 3 * w.n_unit, iM, D, 3 * w.n_unit);
@@ -933,14 +979,22 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         // -- x_out = x_mid + conv_module(x_mid)
         PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
              hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, b.x_mid, L.cm_ln_w, L.cm_ln_b, M, b.y2));
-        {
-            gemm::Args g = gemm::make(b.y2, D, L.cm_pw1_w, D, iM, 2 * INNER, D);
-            gemm::EpiStore e{b.g1, 2 * INNER, L.cm_pw1_b, 1, 0, 0};
-            PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * 2 * INNER * D, 4.0 * M * (D + 2 * INNER),
-                 (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
+        if (fuse_glu) {
+            gemm::Args g = gemm::make(b.y2, D, bf.wglu + (size_t)l * 2 * INNER * D, D, iM, 2 * INNER, D);
+            EpiGlu e{b.glu, bf.bglu + (size_t)l * 2 * INNER};
+            DDSP_REQUIRE(ctx, gemm::dma_ok(g) && ((uintptr_t)b.glu % 16) == 0, "unit2ctrl: fused GLU needs aligned activations");
+            PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * 2 * INNER * D, 4.0 * M * (D + INNER),
+                 (gemm::launch_dma<128, 128, EpiGlu, 2>(st, g, 1, e)));
+        } else {
+            {
+                gemm::Args g = gemm::make(b.y2, D, L.cm_pw1_w, D, iM, 2 * INNER, D);
+                gemm::EpiStore e{b.g1, 2 * INNER, L.cm_pw1_b, 1, 0, 0};
+                PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * 2 * INNER * D, 4.0 * M * (D + 2 * INNER),
+                     (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
+            }
+            PROF(PF_U2C_ROWWISE, 0, 12.0 * M * INNER,
+                 hipLaunchKernelGGL(glu_kernel, dim3(grid_for(M * (INNER / 4))), dim3(256), 0, st, b.g1, M, b.glu));
         }
-        PROF(PF_U2C_ROWWISE, 0, 12.0 * M * INNER,
-             hipLaunchKernelGGL(glu_kernel, dim3(grid_for(M * (INNER / 4))), dim3(256), 0, st, b.g1, M, b.glu));
         PROF(PF_U2C_ROWWISE, 2.0 * M * INNER * DWK, 8.0 * M * INNER,
              hipLaunchKernelGGL((dwconv_kernel<true, false>), dim3(INNER / 256, (unsigned)(B * ((Fr + DW_RUN - 1) / DW_RUN))),
                                 dim3(256), 0, st, b.glu, L.cm_dw_w, L.cm_dw_b, (int)B, (int)Fr, b.dwo, b.pre));

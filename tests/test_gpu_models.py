@@ -27,6 +27,41 @@ def _to(d, dev):
     return {k: v.to(dev) for k, v in d.items()}
 
 
+def test_unit2ctrl_large_batch_fused_glu_matches_oracle(dev, lib_path):
+    """From 8065 rows on, inference forms the conformer's GLU inside the pw1 GEMM (gated-pair epilogue on re-ordered
+    weights, unit2ctrl.hip).  The small parity cases never reach that path, so this one does: B*Fr = 8256 rows against
+    the oracle at the same tolerances, plus a check (launch counts of the row-kernel family) that the fused path is
+    the one that ran."""
+    import hipddsp
+    model, cfg = synthetic.build_model("CombSub", seed=99)
+    sd = {k[len("unit2ctrl."):]: v for k, v in model.state_dict().items() if k.startswith("unit2ctrl.")}
+    B, Fr = 48, 172
+    inp = synthetic.make_inputs(77, B, Fr, with_noise=False)
+    phase = torch.from_numpy(np.random.Generator(np.random.PCG64(6)).uniform(-np.pi, np.pi, (B, Fr)).astype(np.float32))
+    with torch.no_grad():
+        want = OC.unit2control(sd, inp["units"], inp["f0"], phase, inp["volume"], inp["spk_id"], None,
+                               model.unit2ctrl.output_splits, return_flat=True)
+    model = model.to(dev).eval()
+    ctx = hipddsp.context_for(dev)
+
+    def run(nb):
+        args = [inp[k][:nb].to(dev) for k in ("units", "f0")] + [phase[:nb].to(dev), inp["volume"][:nb].to(dev),
+                                                                 inp["spk_id"][:nb].to(dev)]
+        ctx.profile_begin(["u2c_rowwise"])
+        with torch.no_grad():
+            out = model.unit2ctrl.forward_flat(*args, None)
+        return out.cpu(), ctx.profile_end()["u2c_rowwise"]["launches"]
+
+    got, launches_big = run(B)
+    small, launches_small = run(2)
+    assert launches_big == launches_small - 3, (launches_big, launches_small)   # three glu kernels fewer
+    assert got.shape == want.shape
+    assert (got - want).abs().max() < 2e-4
+    assert rms(got - want) < 2e-5
+    # the unfused small batch agrees with the fused large one on the rows they share
+    assert (small - got[:2]).abs().max() < 2e-5
+
+
 @pytest.mark.parametrize("B,Fr", [(2, 12), (3, 172), (1, 87)])
 @pytest.mark.parametrize("spk_mode", ["per_row", "broadcast", "mix"])
 def test_unit2ctrl_matches_oracle(dev, lib_path, B, Fr, spk_mode):
