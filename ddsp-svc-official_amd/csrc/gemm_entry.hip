@@ -27,6 +27,8 @@ extern "C" int ddsp_gemm_f32(ddsp_ctx* ctx, void* stream, const float* A, int64_
         else if (tile == 12) gemm::launch_dma<256, 128>(st, g, 1, e);
         else if (tile == 13) gemm::launch_dma<128, 128, gemm::EpiStore, 2>(st, g, 1, e);
         else if (tile == 14) gemm::launch_dma<128, 64, gemm::EpiStore, 2>(st, g, 1, e);
+        else if (tile == 15) gemm::launch_dma<64, 64, gemm::EpiStore, 3, 0, 4>(st, g, 1, e);   // 4 waves, 64x64
+        else if (tile == 16) gemm::launch_dma<64, 128, gemm::EpiStore, 3, 0, 4>(st, g, 1, e);  // 4 waves, 64x128
         else if (tile == 20) gemm::launch_dma<128, 64, gemm::EpiStore, 3, 1>(st, g, 1, e);   // no MFMA (timing only)
         else if (tile == 21) gemm::launch_dma<128, 64, gemm::EpiStore, 3, 2>(st, g, 1, e);   // no DMA (timing only)
         else if (tile == 22) gemm::launch_dma<128, 64, gemm::EpiStore, 3, 6>(st, g, 1, e);   // no DMA, no stores

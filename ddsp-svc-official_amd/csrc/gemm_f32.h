@@ -325,9 +325,11 @@ __global__ void __launch_bounds__(64 * NW) kernel(Args g, Epi epi) {
 // address), so that the MFMA operand fetch - lane (i = l&31, h = l>>5) reads its 16 k-values 16h..16h+15 of row i
 // as four ds_read_b128 - is bank-conflict-free.  The MFMA k-order is permuted (step s of lane half h is
 // k = 16h + s) identically for A and B, which leaves the sum unchanged.
-template <int BM, int BN, class Epi, int NS = 3, int ABLATE = 0>  // ABLATE bit mask (timing experiments only): 1 no MFMA, 2 no DMA, 4 no epilogue stores, 8 no barrier
-__global__ void __launch_bounds__(512, (BM * BN <= 128 * 128 ? 4 : 2)) kernel_dma(Args g, Epi epi, int tiles_m, int tiles_n, int total_tiles) {
-    constexpr int NW = 8, WGM = 4, WGN = 2;
+// NW = 8 waves as a 4(M) x 2(N) grid, or NW = 4 as 2 x 2 (64x64 tiles: four times as many workgroups for the skinny
+// N = 256 layers, whose 128-row tilings leave a third of the CUs without work).
+template <int BM, int BN, class Epi, int NS = 3, int ABLATE = 0, int NW = 8>  // ABLATE bit mask (timing experiments only): 1 no MFMA, 2 no DMA, 4 no epilogue stores, 8 no barrier
+__global__ void __launch_bounds__(64 * NW, (BM * BN <= 128 * 128 ? 4 : 2)) kernel_dma(Args g, Epi epi, int tiles_m, int tiles_n, int total_tiles) {
+    constexpr int WGM = NW / 2, WGN = 2;
     constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
     constexpr int ROWS = BM + BN;            // rows per stage
     constexpr int STAGE = ROWS * 32;         // floats per stage
@@ -535,16 +537,18 @@ inline bool dma_ok(const Args& g) {
            g.sA_hi % 4 == 0 && g.sA_lo % 4 == 0 && g.sB_hi % 4 == 0 && g.sB_lo % 4 == 0;
 }
 
-template <int BM, int BN, class Epi, int NS = 3, int ABLATE = 0>
+template <int BM, int BN, class Epi, int NS = 3, int ABLATE = 0, int NW = 8>
 inline void launch_dma(hipStream_t st, const Args& g, int batch, const Epi& epi) {
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
     const int total = tiles_m * tiles_n * batch;
     // resident workgroups per CU by LDS (NS stages of (BM+BN) x 128 B), 8 waves each
     constexpr int lds_bytes = NS * (BM + BN) * 128;
-    constexpr int per_cu = (160 * 1024 / lds_bytes) < 2 ? (160 * 1024 / lds_bytes) : 2;
+    constexpr int by_waves = 16 / NW;   // 4 waves per SIMD
+    constexpr int by_lds = 160 * 1024 / lds_bytes;
+    constexpr int per_cu = by_lds < by_waves ? by_lds : by_waves;
     int grid = 256 * per_cu;
     if (grid > total) grid = total;
-    hipLaunchKernelGGL((kernel_dma<BM, BN, Epi, NS, ABLATE>), dim3(grid), dim3(512), 0, st, g, epi, tiles_m, tiles_n, total);
+    hipLaunchKernelGGL((kernel_dma<BM, BN, Epi, NS, ABLATE, NW>), dim3(grid), dim3(64 * NW), 0, st, g, epi, tiles_m, tiles_n, total);
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC, int A_MODE, class Epi, int NW = 4>
@@ -567,9 +571,14 @@ inline void launch(hipStream_t st, const Args& g, int batch, const Epi& epi) {
     if constexpr (A_KC && B_KC && A_MODE == A_PLAIN) {
         if (dma_ok(g) && blocks(128, 64) >= 256) {
             // 128x128 tiles (32 FLOP per staged byte, 2-stage ring, 2 workgroups per CU) when they still fill the
-            // 512 resident slots, or when N is so small that the 128x64 grid is half empty anyway; else 128x64
+            // 512 resident slots; else 128x64
             // tiles with the 3-stage ring (tools/gemm_ab.py: N=1024 86 vs 78, N=256 67-72 vs 65-68, N=512 59 vs 70)
-            if (blocks(128, 128) >= 512 || g.N <= 256)
+            // ... and 64x64 tiles on 4 waves for the skinny N <= 256 layers: 128-row tilings give them at most 344
+            // workgroups (a third of the CUs idle or doubly loaded), 64x64 gives 688 on 768 slots
+            // (tools/gemm_ab.py, M=11008: N=256 K=512 35.3 vs 38.8 us, K=768 49.2 vs 54.8 us)
+            if (g.N <= 256)
+                launch_dma<64, 64, Epi, 3, 0, 4>(st, g, batch, epi);
+            else if (blocks(128, 128) >= 512)
                 launch_dma<128, 128, Epi, 2>(st, g, batch, epi);
             else
                 launch_dma<128, 64, Epi, 3>(st, g, batch, epi);

@@ -13,7 +13,7 @@ for (M, N, K) in shapes:
     B = torch.randn(N, K, device=dev)
     ref = A @ B.t()
     res = {}
-    for tile in (10, 13, 14, 21):
+    for tile in (10, 13, 15, 16):
         for var in (0,):
             C = ctx.gemm(A, B, tile=tile, variant=var)
             err = float((C - ref).abs().max())
