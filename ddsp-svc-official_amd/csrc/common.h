@@ -49,6 +49,8 @@ struct ddsp_ctx {
     // packed control-net weights (prepared by ddsp_u2c_prepare)
     float* packed;
     size_t packed_bytes;
+    // 8 KiB of zeros: the source of out-of-range conv taps in the LDS-DMA GEMM (a DMA cannot be predicated to zero)
+    float* zero_page;
 };
 
 static inline int ddsp_fail(ddsp_ctx* ctx, int code, const char* what, const char* detail) {
@@ -79,6 +81,9 @@ int ddsp_scratch_get(ddsp_ctx* ctx, size_t bytes, void** out);
 int ddsp_scratch_reserve_bytes(ddsp_ctx* ctx, size_t bytes);
 // tables (tables.hip)
 int ddsp_get_table(ddsp_ctx* ctx, hipStream_t st, int kind, int n0, int n1, float** out);
+// device pointer to DDSP_ZERO_FLOATS zeros (allocated on first use; a first-use synchronisation like the tables)
+constexpr int DDSP_ZERO_FLOATS = 2048;
+int ddsp_zero_page(ddsp_ctx* ctx, const float** out);
 
 // profiler hooks (ctx.hip): bracket ONE kernel launch (or a tight group) on `st` when the family is enabled
 void ddsp_prof_begin(ddsp_ctx* ctx, hipStream_t st, int id);

@@ -32,6 +32,7 @@ extern "C" int ddsp_ctx_destroy(ddsp_ctx* ctx) {
     (void)hipDeviceSynchronize();
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->packed) (void)hipFree(ctx->packed);
+    if (ctx->zero_page) (void)hipFree(ctx->zero_page);
     if (ctx->prof) {
         for (int i = 0; i < ctx->prof_events_made; ++i) {
             (void)hipEventDestroy(ctx->prof[i].start);
@@ -146,5 +147,22 @@ extern "C" int ddsp_profile_end(ddsp_ctx* ctx, ddsp_prof_entry* out, int max_ent
     }
     *n_entries = n;
     ctx->prof_n = 0;
+    return DDSP_OK;
+}
+
+int ddsp_zero_page(ddsp_ctx* ctx, const float** out) {
+    if (!ctx->zero_page) {
+        DDSP_HIP(ctx, hipSetDevice(ctx->device));
+        float* p = nullptr;
+        hipError_t e = hipMalloc((void**)&p, DDSP_ZERO_FLOATS * sizeof(float));
+        if (e != hipSuccess) return ddsp_fail(ctx, DDSP_ERR_OOM, "zero page hipMalloc", hipGetErrorString(e));
+        e = hipMemset(p, 0, DDSP_ZERO_FLOATS * sizeof(float));
+        if (e != hipSuccess) {
+            (void)hipFree(p);
+            return ddsp_fail(ctx, DDSP_ERR_HIP, "zero page hipMemset", hipGetErrorString(e));
+        }
+        ctx->zero_page = p;
+    }
+    *out = ctx->zero_page;
     return DDSP_OK;
 }

@@ -41,6 +41,7 @@ struct Args {
     int64_t sA_hi, sA_lo, sB_hi, sB_lo;
     // conv3 mode
     int Fr, Cin;
+    const float* zeros;   // >= Cin + 32 zero floats (DMA kernel, conv3 mode: source of the taps that fall off an utterance)
 };
 
 constexpr int BK = 32;
@@ -327,7 +328,7 @@ __global__ void __launch_bounds__(64 * NW) kernel(Args g, Epi epi) {
 // k = 16h + s) identically for A and B, which leaves the sum unchanged.
 // NW = 8 waves as a 4(M) x 2(N) grid, or NW = 4 as 2 x 2 (64x64 tiles: four times as many workgroups for the skinny
 // N = 256 layers, whose 128-row tilings leave a third of the CUs without work).
-template <int BM, int BN, class Epi, int NS = 3, int ABLATE = 0, int NW = 8>  // ABLATE bit mask (timing experiments only): 1 no MFMA, 2 no DMA, 4 no epilogue stores, 8 no barrier
+template <int BM, int BN, class Epi, int NS = 3, int ABLATE = 0, int NW = 8, int A_MODE = A_PLAIN>  // ABLATE bit mask (timing experiments only): 1 no MFMA, 2 no DMA, 4 no epilogue stores, 8 no barrier
 __global__ void __launch_bounds__(64 * NW, (BM * BN <= 128 * 128 ? 4 : 2)) kernel_dma(Args g, Epi epi, int tiles_m, int tiles_n, int total_tiles) {
     constexpr int WGM = NW / 2, WGN = 2;
     constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
@@ -351,6 +352,13 @@ __global__ void __launch_bounds__(64 * NW, (BM * BN <= 128 * 128 ? 4 : 2)) kerne
 
     // per-lane source pointers (k = 0) of this wave's DMA pieces for a given tile; rows past the edge re-read
     // the last row (their products are never stored)
+    // conv3 mode (implicit im2col, k = tap*Cin + c, A[m][k] = X[m + tap - 1][c] inside the utterance, else 0): the A
+    // pieces keep one source pointer per tap; a tap that falls off the utterance points at the zero page.  Cin % 32 == 0,
+    // so a k-step never straddles taps and the tap is wave-uniform.
+    constexpr int PA = (BM / 8) / NW;        // this wave's pieces i < PA are A rows, the others B rows
+    static_assert((BM / 8) % NW == 0, "A rows must split evenly over the waves");
+    const float* src_m1[PA];                 // taps 0 and 2 (tap 1 lives in src[])
+    const float* src_p1[PA];
     auto tile_src = [&](int tile, const float* (&src)[PPW]) {
         const int per_z = tiles_m * tiles_n;
         const int z = tile / per_z, rem = tile - z * per_z;
@@ -366,6 +374,13 @@ __global__ void __launch_bounds__(64 * NW, (BM * BN <= 128 * 128 ? 4 : 2)) kerne
                 int m = m0 + row;
                 m = m < g.M ? m : g.M - 1;
                 src[i] = A + (int64_t)m * g.lda + slot * 4;
+                if constexpr (A_MODE == A_CONV3) {
+                    if (i < PA) {
+                        const int f = m % g.Fr;
+                        src_m1[i < PA ? i : 0] = f >= 1 ? src[i] - g.lda : g.zeros + slot * 4;
+                        src_p1[i < PA ? i : 0] = f + 1 < g.Fr ? src[i] + g.lda : g.zeros + slot * 4;
+                    }
+                }
             } else {
                 int n = n0 + row - BM;
                 n = n < g.N ? n : g.N - 1;
@@ -374,10 +389,19 @@ __global__ void __launch_bounds__(64 * NW, (BM * BN <= 128 * 128 ? 4 : 2)) kerne
         }
     };
     auto issue = [&](const float* const (&src)[PPW], int kt, int stage) {
+        int tap = 1, koff = kt * 32;
+        if constexpr (A_MODE == A_CONV3) {
+            tap = koff / g.Cin;
+            koff -= tap * g.Cin;
+        }
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int piece = wave + NW * i;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + kt * 32),
+            const float* p = src[i] + kt * 32;
+            if constexpr (A_MODE == A_CONV3) {
+                if (i < PA) p = (tap == 0 ? src_m1[i < PA ? i : 0] : tap == 1 ? src[i] : src_p1[i < PA ? i : 0]) + koff;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                              (__attribute__((address_space(3))) void*)(lds + stage * STAGE + piece * 256),
                                              16, 0, 0);
         }
@@ -537,7 +561,7 @@ inline bool dma_ok(const Args& g) {
            g.sA_hi % 4 == 0 && g.sA_lo % 4 == 0 && g.sB_hi % 4 == 0 && g.sB_lo % 4 == 0;
 }
 
-template <int BM, int BN, class Epi, int NS = 3, int ABLATE = 0, int NW = 8>
+template <int BM, int BN, class Epi, int NS = 3, int ABLATE = 0, int NW = 8, int A_MODE = A_PLAIN>
 inline void launch_dma(hipStream_t st, const Args& g, int batch, const Epi& epi) {
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
     const int total = tiles_m * tiles_n * batch;
@@ -548,7 +572,7 @@ inline void launch_dma(hipStream_t st, const Args& g, int batch, const Epi& epi)
     constexpr int per_cu = by_lds < by_waves ? by_lds : by_waves;
     int grid = 256 * per_cu;
     if (grid > total) grid = total;
-    hipLaunchKernelGGL((kernel_dma<BM, BN, Epi, NS, ABLATE, NW>), dim3(grid), dim3(64 * NW), 0, st, g, epi, tiles_m, tiles_n, total);
+    hipLaunchKernelGGL((kernel_dma<BM, BN, Epi, NS, ABLATE, NW, A_MODE>), dim3(grid), dim3(64 * NW), 0, st, g, epi, tiles_m, tiles_n, total);
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC, int A_MODE, class Epi, int NW = 4>
@@ -568,6 +592,14 @@ inline void launch(hipStream_t st, const Args& g, int batch, const Epi& epi) {
     auto blocks = [&](int bm, int bn) {
         return (int64_t)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch;
     };
+    if constexpr (A_KC && B_KC && A_MODE == A_CONV3) {
+        // implicit-im2col convs (N = 256): the 4-wave 64x64 DMA tile with one source pointer per tap
+        if (dma_ok(g) && g.zeros && g.Cin % 32 == 0 && g.Cin + 32 <= DDSP_ZERO_FLOATS && g.N <= 256 &&
+            blocks(64, 64) >= 256) {
+            launch_dma<64, 64, Epi, 3, 0, 4, A_CONV3>(st, g, batch, epi);
+            return;
+        }
+    }
     if constexpr (A_KC && B_KC && A_MODE == A_PLAIN) {
         if (dma_ok(g) && blocks(128, 64) >= 256) {
             // 128x128 tiles (32 FLOP per staged byte, 2-stage ring, 2 workgroups per CU) when they still fill the
@@ -604,6 +636,7 @@ inline Args make(const float* A, int64_t lda, const float* B, int64_t ldb, int M
     g.sA_hi = g.sA_lo = g.sB_hi = g.sB_lo = 0;
     g.Fr = 1;
     g.Cin = 4;
+    g.zeros = nullptr;
     return g;
 }
 

@@ -859,6 +859,8 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
     const int64_t B = in.B, Fr = in.Fr, M = B * Fr, M8 = M * H;
     const int iM = (int)M;
     const size_t n_w1 = (size_t)D * 3 * w.n_unit, n_w2 = (size_t)D * 3 * D, n_wh = (size_t)w.n_out * D;
+    const float* zero_page = nullptr;   // source of the conv taps that fall off an utterance (LDS-DMA conv GEMM)
+    if (int rc = ddsp_zero_page(ctx, &zero_page)) return rc;
     PROF(PF_U2C_PREP, 0, 8.0 * (n_w1 + n_w2 + n_wh),
          hipLaunchKernelGGL(pack_conv3_kernel, dim3(grid_for(n_w1)), dim3(256), 0, st, w.prenet_conv1_w, D, w.n_unit, bf.w1);
          hipLaunchKernelGGL(pack_conv3_kernel, dim3(grid_for(n_w2)), dim3(256), 0, st, w.prenet_conv2_w, D, D, bf.w2);
@@ -887,6 +889,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         gemm::Args g = gemm::make(in.units, w.n_unit, bf.w1, 3 * w.n_unit, iM, D, 3 * w.n_unit);
         g.Fr = (int)Fr;
         g.Cin = w.n_unit;
+        g.zeros = zero_page;
         gemm::EpiStore e{bf.t1, D, w.prenet_conv1_b, 1, 0, 0};
         PROF(PF_U2C_GEMM_CONV3, 2.0 * M * D * 3 * w.n_unit, 4.0 * M * (w.n_unit + D),
              (gemm::launch<true, true, gemm::A_CONV3>(st, g, 1, e)));
@@ -901,6 +904,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         gemm::Args g = gemm::make(bf.t2, D, bf.w2, 3 * D, iM, D, 3 * D);
         g.Fr = (int)Fr;
         g.Cin = D;
+        g.zeros = zero_page;
         gemm::EpiStore e{x, D, w.prenet_conv2_b, 1, 0, 0};
         PROF(PF_U2C_GEMM_CONV3, 2.0 * M * D * 3 * D, 8.0 * M * D, (gemm::launch<true, true, gemm::A_CONV3>(st, g, 1, e)));
     }
@@ -1332,6 +1336,7 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
         gemm::Args g = gemm::make(dX, D, w2t, 3 * D, (int)M, D, 3 * D);
         g.Fr = (int)Fr;
         g.Cin = D;
+        if (int rc = ddsp_zero_page(ctx, &g.zeros)) return rc;
         gemm::EpiStore e{dA, D, nullptr, 1, 0, 0};
         gemm::launch<true, true, gemm::A_CONV3>(st, g, 1, e);                                      // d_t2
     }

@@ -84,7 +84,9 @@ def test_fir_from_ctrl_adjoint(ctx, dev, mode, n_mag):
 
 
 # ---- control network backward -------------------------------------------------------------------------
-@pytest.mark.parametrize("B,Fr,spk_mode", [(2, 12, "per_row"), (3, 40, "broadcast"), (2, 172, "mix")])
+# (24, 172): 4128 rows - from 4033 rows on the prenet convs (forward recompute AND the d_t2 adjoint) run the LDS-DMA
+# implicit-im2col GEMM instead of the register-staged one, and the N <= 256 layers the 4-wave 64x64 tile
+@pytest.mark.parametrize("B,Fr,spk_mode", [(2, 12, "per_row"), (3, 40, "broadcast"), (2, 172, "mix"), (24, 172, "per_row")])
 def test_unit2ctrl_parameter_gradients(dev, lib_path, B, Fr, spk_mode):
     import synthetic
     from oracle import ctrlnet as OC
