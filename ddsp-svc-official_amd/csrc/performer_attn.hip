@@ -122,10 +122,17 @@ __global__ void __launch_bounds__(256, 4) performer_kv_kernel(const float* __res
         float ss = 0.f;
 #pragma unroll
         for (int s = 0; s < 16; ++s) ss = fmaf(ka[s], ka[s], ss);
+        // two independent accumulator chains (even / odd k-steps), summed afterwards: a 16x16x4 MFMA that accumulates
+        // onto the previous one's result cannot issue until that result is written
         f32x4_t S = ft == n_ft - 1 ? c_last : c_full;
+        f32x4_t S2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 16; ++s) S = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[s], pb[s], S, 0, 0, 0);
-        S = __builtin_amdgcn_mfma_f32_16x16x4f32(ss, NEG_HALF, S, 0, 0, 0);
+        for (int s = 0; s < 16; s += 2) {
+            S = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[s], pb[s], S, 0, 0, 0);
+            S2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[s + 1], pb[s + 1], S2, 0, 0, 0);
+        }
+        S2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ss, NEG_HALF, S2, 0, 0, 0);
+        S += S2;
         f32x4_t kf;
 #pragma unroll
         for (int r = 0; r < 4; ++r) kf[r] = __builtin_amdgcn_exp2f(S[r]);   // row 4g+r = frame within the tile
@@ -213,8 +220,13 @@ __global__ void __launch_bounds__(256, 4) performer_q_kernel(const float* __rest
         jn = jn < NF ? jn : NF - 1;
         load_quarter_row(P + jn * DH + 16 * g, pn);
         f32x4_t S = jt == NJT - 1 ? c_last : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        f32x4_t S2 = {0.f, 0.f, 0.f, 0.f};           // (two independent chains, see the K kernel)
 #pragma unroll
-        for (int s = 0; s < 16; ++s) S = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s], qb[s], S, 0, 0, 0);
+        for (int s = 0; s < 16; s += 2) {
+            S = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s], qb[s], S, 0, 0, 0);
+            S2 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s + 1], qb[s + 1], S2, 0, 0, 0);
+        }
+        S += S2;
         const float tmax = group_max(fmaxf(fmaxf(S[0], S[1]), fmaxf(S[2], S[3])));
         const float m_new = fmaxf(m_run, tmax);
         const float sc = __builtin_amdgcn_exp2f(m_run - m_new);
