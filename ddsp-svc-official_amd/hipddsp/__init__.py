@@ -67,6 +67,7 @@ SIGNATURES = {
     "ddsp_sola": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp]),
     "ddsp_volume_gate": (_int, [_vp, _vp, _vp, _vp, _f32, _i64, _i64, _int]),
     "ddsp_adamw_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64]),
+    "ddsp_adamw_step_multi": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _i64]),
     "ddsp_gemm_f32": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _i64, _int, _vp, _vp, _i64, _int, _int, _int, _int, _int]),
     "ddsp_profile_begin": (_int, [_vp, _u64]),
     "ddsp_profile_end": (_int, [_vp, _c.POINTER(ProfEntry), _int, _c.POINTER(_int)]),
@@ -285,6 +286,23 @@ class Context:
     # -- a15 optimiser -------------------------------------------------------------------------
     def adamw_step(self, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):
         self.call("ddsp_adamw_step", _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), float(lr),
+                  float(beta1), float(beta2), float(eps), float(weight_decay), int(step))
+
+    def adamw_step_multi(self, params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, weight_decay, step):
+        """One AdamW update of a whole list of parameter tensors (shared hyper-parameters and step): the pointer
+        tables go to the library as host arrays, the library issues one launch per 24 tensors."""
+        n = len(params)
+        if not (len(grads) == len(exp_avgs) == len(exp_avg_sqs) == n):
+            raise ValueError("adamw_step_multi: lists of different length")
+        for t in (*params, *grads, *exp_avgs, *exp_avg_sqs):
+            if t.dtype != torch.float32:
+                raise ValueError("adamw_step_multi: fp32 tensors only")
+        for p, g, m, v in zip(params, grads, exp_avgs, exp_avg_sqs):
+            if not (g.numel() == m.numel() == v.numel() == p.numel()):
+                raise ValueError("adamw_step_multi: a tensor and its state differ in size")
+        arr = lambda ts: (_vp * n)(*[_ptr(t) for t in ts])
+        numel = (_i64 * n)(*[p.numel() for p in params])
+        self.call("ddsp_adamw_step_multi", n, arr(params), arr(grads), arr(exp_avgs), arr(exp_avg_sqs), numel, float(lr),
                   float(beta1), float(beta2), float(eps), float(weight_decay), int(step))
 
     # -- building block ------------------------------------------------------------------------

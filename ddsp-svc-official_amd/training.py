@@ -20,6 +20,8 @@ class AdamW(torch.optim.Optimizer):
                 loss = closure()
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            # parameters that can share one library call: same device, same step count, contiguous storage
+            batches = {}
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -28,12 +30,17 @@ class AdamW(torch.optim.Optimizer):
                 st = self.state[p]
                 if not st:
                     st["step"] = torch.tensor(0.0)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
+                if not p.data.is_contiguous():
+                    raise ValueError("AdamW kernel needs contiguous parameters")
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                hipddsp.context_for(p.device).adamw_step(p.data, g, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2,
-                                                         group["eps"], group["weight_decay"], int(st["step"]))
+                batches.setdefault((p.device, int(st["step"])), []).append((p.data, g, st["exp_avg"], st["exp_avg_sq"]))
+            for (device, step), items in batches.items():
+                ps, gs, ms, vs = zip(*items)
+                hipddsp.context_for(device).adamw_step_multi(ps, gs, ms, vs, group["lr"], b1, b2, group["eps"],
+                                                             group["weight_decay"], step)
         return loss
 
 

@@ -199,6 +199,12 @@ int ddsp_volume_gate(ddsp_ctx* ctx, void* stream, float* signal, const float* vo
  * bias-corrected moments, `step` counted from 1.  All buffers hold n fp32 values. */
 int ddsp_adamw_step(ddsp_ctx* ctx, void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                     int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step);
+/* the same update for n_tensors parameters that share hyper-parameters and step (one optimizer.step() of
+ * solver.py:114 over a param group), a handful of launches instead of one per tensor.  params / grads / exp_avg /
+ * exp_avg_sq are HOST arrays of n_tensors device pointers, numel a host array of element counts (0 allowed). */
+int ddsp_adamw_step_multi(ddsp_ctx* ctx, void* stream, int n_tensors, float* const* params, const float* const* grads,
+                          float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel, float lr,
+                          float beta1, float beta2, float eps, float weight_decay, int64_t step);
 
 /* ---- building block: fp32-in / fp32-accumulate MFMA GEMM ---------------------------------------- */
 /* C[m][n] = sum_k A(m,k) B(k,n) (+ bias[n]).  a_k_contig: A(m,k) = A[m*lda+k] else A[k*lda+m];

@@ -114,6 +114,41 @@ def test_adamw_matches_torch(dev, lib_path):
     assert (a.detach() - b.detach().cpu()).abs().max() < 2e-6
 
 
+def test_adamw_many_tensors_matches_torch(dev, lib_path):
+    """The optimizer updates a whole parameter group through ddsp_adamw_step_multi (24 tensors per launch): 61 tensors
+    of awkward sizes (1 element, one short of / one past a 2048-element block, empty, some without a gradient) over
+    three steps against torch.optim.AdamW, and against the one-tensor entry point bit for bit."""
+    import training, hipddsp
+    torch.manual_seed(1)
+    sizes = [1, 3, 255, 256, 257, 2047, 2048, 2049, 4097, 100003, 0] + [int(x) for x in torch.randint(1, 5000, (50,))]
+    p0 = [torch.randn(n) for n in sizes]
+    a = [torch.nn.Parameter(t.clone()) for t in p0]
+    b = [torch.nn.Parameter(t.clone().to(dev)) for t in p0]
+    c = [t.clone().to(dev) for t in p0]                        # updated through ddsp_adamw_step, tensor by tensor
+    cm = [torch.zeros_like(t) for t in c]
+    cv = [torch.zeros_like(t) for t in c]
+    oa = torch.optim.AdamW(a, lr=2e-3, betas=(0.8, 0.95), eps=1e-7, weight_decay=0.05)
+    ob = training.AdamW(b, lr=2e-3, betas=(0.8, 0.95), eps=1e-7, weight_decay=0.05)
+    ctx = hipddsp.context_for(dev)
+    no_grad = {5, 17}                                           # parameters the loss did not touch
+    for step in range(1, 4):
+        for i, n in enumerate(sizes):
+            g = None if i in no_grad else torch.randn(n) * 0.1
+            a[i].grad = g
+            b[i].grad = None if g is None else g.to(dev)
+            if g is not None and n > 0:
+                ctx.adamw_step(c[i], g.to(dev), cm[i], cv[i], 2e-3, 0.8, 0.95, 1e-7, 0.05, step)
+        oa.step()
+        ob.step()
+    for i, n in enumerate(sizes):
+        assert torch.equal(b[i].detach(), c[i]), i             # same arithmetic as the per-tensor kernel
+        if n:
+            assert (a[i].detach() - b[i].detach().cpu()).abs().max() < 2e-6, i
+    assert torch.equal(b[5].detach().cpu(), p0[5])              # untouched without a gradient
+    with pytest.raises(ValueError):
+        ctx.adamw_step_multi([c[0]], [c[1]], [cm[0]], [cv[0]], 1e-3, 0.9, 0.999, 1e-8, 0.0, 1)
+
+
 def test_loss_decreases_over_steps(dev, lib_path):
     import training
     from ddsp.loss import RSSLoss
