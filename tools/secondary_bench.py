@@ -47,4 +47,7 @@ def rt():
         return sp.push(sig[0])
 t = timeit(rt, n=50, warm=5)
 out["realtime_block_B1"] = {"ms_per_block": t * 1e3, "block_ms_of_audio": 200.0, "x_realtime": 0.2 / t}
+# (the model constructors print a banner line each; the JSON goes to its own file when a path is given)
+if len(sys.argv) > 1:
+    json.dump(out, open(sys.argv[1], "w"), indent=1)
 print(json.dumps(out, indent=1))
