@@ -45,7 +45,7 @@ def measured_traffic():
     d = json.load(open(files[-1]))
     tot = n = 0.0
     for k, v in d.items():
-        if "kernel_dma" in k:
+        if "kernel_dma" in k and ", 1>(" not in k:     # Linear layers only (A_MODE 1 = the prenet convs' instantiation)
             tot += v["hbm_bytes_per_launch"] * v["launches_sampled"]
             n += v["launches_sampled"]
     return tot / n if n else None
