@@ -32,9 +32,50 @@ def fo_to_rot(fo, sr, initial_phase=None, precise=False):
     return out["rot"].to(fo.dtype)
 
 
+def _impulse_response(magnitudes, hann_window=True, half_width_frames=None):
+    """Frequency responses (B, Frame, n_mag) complex -> causal impulse responses (B, Frame, n = 2*(n_mag-1)).
+
+    Restates reference `ddsp/core.py:296-327` (and its two window helpers, `:241-293`) as index arithmetic on the
+    zero-phase response h = irfft(magnitudes):  g[i] = h[(i - n/2) mod n] * w[i]  with
+      * no window:       w = 1
+      * static window:   w = periodic Hann of length n  (window and response are both rotated by n/2 there)
+      * dynamic window:  x = (i - n/2) / half_width;  x > 1 is set to 0 BEFORE the raised cosine (so the weight is 1,
+                         not 0) and x < -1 is not clamped - both as the reference does it.
+    Device ops of PyTorch (rocFFT inverse real FFT + elementwise); the models never call this - their filters come
+    from `ddsp_fir_from_ctrl`, which fuses the activations and the inverse DFT into one MFMA GEMM.
+    """
+    h = torch.fft.irfft(magnitudes)
+    n = h.shape[-1]
+    i = torch.arange(n, device=h.device)
+    g = h.index_select(-1, (i - n // 2) % n)
+    if not hann_window:
+        return g
+    if half_width_frames is None:
+        return g * (0.5 - 0.5 * torch.cos(i.to(h.dtype) * (2.0 * torch.pi / n)))
+    x = (i - n // 2).to(h.dtype) / half_width_frames.to(h.dtype)
+    x = torch.where(x > 1, torch.zeros_like(x), x)
+    return g * ((1 + torch.cos(torch.pi * x)) / 2)
+
+
 def frequency_filter(audio, magnitudes, hann_window=True, half_width_frames=None):
-    """LTV-FIR from frequency responses (reference `ddsp/core.py:331-336`) is exposed at the control
-    level on the device path: use `hipddsp.Context.fir_from_ctrl` + `.ltv_fir` (the exp / tanh-cumsum
-    activations are fused into the filter synthesis, so the complex `magnitudes` tensor of the
-    reference is never materialised)."""
-    raise NotImplementedError("use hipddsp.Context.fir_from_ctrl/ltv_fir (control-level API); see INTEGRATION.md")
+    """Linear time-varying FIR filtering from per-frame frequency responses (reference `ddsp/core.py:331-336`).
+
+    audio :: (B, T) device tensor, magnitudes :: (B, Frame, n_mag) complex, half_width_frames :: (B, Frame, 1) or None.
+    The impulse responses are formed with device ops of PyTorch (`_impulse_response`), the filtering itself -
+    `_fft_convolve`, `core.py:190-238`: 50 %-overlapped Bartlett frames, one filter per frame, output delayed by
+    n/2 and cropped to T - is the hand-written `ddsp_ltv_fir` kernel.  That kernel supports what the models use:
+    T = Frame * 512 and even filter lengths 32..2046 (n_mag 17..1024); other shapes raise ValueError.  Forward only:
+    the models differentiate through their own fused path, so tensors that require grad are refused here.
+    """
+    if audio.requires_grad or magnitudes.requires_grad or (half_width_frames is not None and half_width_frames.requires_grad):
+        raise NotImplementedError("ddsp.core.frequency_filter is forward-only on the device path; train through the model classes")
+    if audio.dim() != 2 or magnitudes.dim() != 3 or audio.shape[0] != magnitudes.shape[0]:
+        raise ValueError("frequency_filter: audio (B, T) and magnitudes (B, Frame, n_mag) expected")
+    B, T = audio.shape
+    Fr = magnitudes.shape[1]
+    if Fr == 0 or T % Fr != 0:
+        raise ValueError("frequency_filter: T must be a whole number of frames on the device path")
+    ir = _impulse_response(magnitudes, hann_window, half_width_frames).float().contiguous()
+    ctx = context_for(audio.device)
+    out, _ = ctx.ltv_fir(audio.float().contiguous(), ir, B, Fr, T // Fr)
+    return out.to(audio.dtype)

@@ -149,3 +149,70 @@ def test_argument_errors(ctx, dev):
         ctx.ltv_fir(x, torch.zeros(1, 2, 510, device=dev), 1, 2, 256)   # hop not built
     with pytest.raises(RuntimeError):
         ctx.upsample(torch.zeros(1, 2, 1), HOP)               # CPU tensor: no fallback
+
+
+# ---- ddsp.core.frequency_filter (the reference's public filter entry point) against the reference's own outputs ----
+def _golden(name):
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
+    return {k: torch.from_numpy(d[k]) for k in d.files}
+
+
+def _responses(ctrl, f0f):
+    """The three complex frequency responses the reference models feed to frequency_filter (as in make_golden.py)."""
+    cz = lambda x: torch.complex(x, torch.zeros_like(x))
+    gd = np.pi * torch.tanh(ctrl[..., :256])
+    return (torch.exp(1.j * torch.cumsum(gd, axis=-1)), cz(torch.exp(ctrl[..., 256:768])),
+            cz(torch.exp(ctrl[..., 768:]) / 128), 1.5 * SR / (f0f + 1e-3))
+
+
+def test_frequency_filter_matches_reference_short(dev, lib_path):
+    """`ddsp.core.frequency_filter` (device impulse responses + the HIP LTV-FIR kernel) on the inputs of
+    tests/golden/core_filter_short.npz, whose y_* were produced by the unmodified reference `ddsp/core.py:331`:
+    all-pass (no window), dynamic window (half widths 1017 and 82: both sides of the window quirk) and static Hann."""
+    from ddsp import core as C
+    g = _golden("core_filter_short.npz")
+    ap, src, nse, hw = _responses(g["ctrl"], g["f0_frames"])
+    d = lambda t: t.to(dev)
+    cases = (("y_ap", g["audio"], ap, False, None), ("y_h", g["y_ap"], src, True, hw), ("y_n", g["audio"], nse, True, None))
+    for key, x, resp, hann, half in cases:
+        got = C.frequency_filter(d(x), d(resp), hann_window=hann, half_width_frames=None if half is None else d(half)).cpu()
+        want = g[key]
+        assert got.shape == want.shape and got.dtype == want.dtype
+        assert rms(got - want) < 2e-5 * max(1.0, rms(want)), (key, rms(got - want), rms(want))
+        assert (got - want).abs().max() < 2e-4 * max(1.0, float(want.abs().max())), key
+
+
+def test_frequency_filter_matches_reference_long(dev, lib_path):
+    """Fr = 172 (one 2 s clip): inputs regenerated from the fixture's seeds, reference outputs stored every 29th sample."""
+    from ddsp import core as C
+    g = _golden("core_filter_long.npz")
+    r = lambda s: np.random.Generator(np.random.PCG64(s))
+    t32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))
+    ctrl = t32(r(310).standard_normal((1, 172, 1024)) * 0.5)
+    f0f = t32(r(311).uniform(65, 800, size=(1, 172, 1)))
+    audio = t32(r(312).uniform(-1, 1, size=(1, 172 * HOP)))
+    ap, src, nse, hw = _responses(ctrl, f0f)
+    d = lambda t: t.to(dev)
+    y_ap = C.frequency_filter(d(audio), d(ap), hann_window=False)
+    y_h = C.frequency_filter(y_ap, d(src), hann_window=True, half_width_frames=d(hw))
+    y_n = C.frequency_filter(d(audio), d(nse), hann_window=True)
+    for got, key, ref_rms in ((y_ap, "y_ap", g["rms"][0]), (y_h, "y_h", g["rms"][1]), (y_n, "y_n", g["rms"][2])):
+        got = got.cpu()
+        assert abs(rms(got) - float(ref_rms)) < 1e-4 * max(1.0, float(ref_rms)), key
+        assert rms(got[:, ::29] - g[key]) < 3e-5 * max(1.0, float(ref_rms)), (key, rms(got[:, ::29] - g[key]))
+
+
+def test_frequency_filter_refusals(dev, lib_path):
+    from ddsp import core as C
+    x = torch.zeros(1, 4 * HOP, device=dev)
+    resp = torch.ones(1, 4, 65, dtype=torch.complex64, device=dev)
+    assert C.frequency_filter(x, resp, hann_window=True).shape == (1, 4 * HOP)
+    with pytest.raises(ValueError):
+        C.frequency_filter(x[:, :-3], resp)                       # not a whole number of frames
+    with pytest.raises(ValueError):
+        C.frequency_filter(torch.zeros(1, 4 * 256, device=dev), resp)   # hop 256: outside what the kernel supports
+    with pytest.raises(NotImplementedError):
+        C.frequency_filter(x.clone().requires_grad_(), resp)     # forward only
+    with pytest.raises(RuntimeError):
+        C.frequency_filter(x.cpu(), resp.cpu())                   # no CPU fallback
