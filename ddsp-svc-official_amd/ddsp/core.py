@@ -20,6 +20,21 @@ def upsample(signal, factor):
     return ctx.upsample(signal, hop).to(signal.dtype)
 
 
+def remove_above_fmax(amplitudes, pitch, fmax, level_start=1):
+    """Anti-aliasing mask of the additive bank (reference `ddsp/core.py:22-26`): harmonic k of a frame keeps its
+    amplitude (times 1 + 1e-7) while k * pitch < fmax and is scaled by 1e-7 above.
+
+    amplitudes :: (B, Frame, H), pitch :: (B, Frame, 1).  Inside `Sins.forward` this mask is applied by the bank
+    kernel itself (`ddsp_sins_bank`); the stand-alone function is three elementwise device ops of PyTorch, kept so
+    that callers of `ddsp.core` find the name.  Device tensors only, like everything here.
+    """
+    if not (amplitudes.is_cuda and pitch.is_cuda):
+        raise RuntimeError("ddsp.core.remove_above_fmax needs device tensors (no CPU fallback)")
+    k = torch.arange(level_start, amplitudes.shape[-1] + level_start, device=pitch.device).to(pitch.dtype)
+    keep = (pitch * k < fmax).to(torch.float32) + 1e-7
+    return amplitudes * keep
+
+
 def fo_to_rot(fo, sr, initial_phase=None, precise=False):
     """Wrapped rotation of a sample-rate fo contour (reference `ddsp/core.py:31-51`).
 

@@ -216,3 +216,13 @@ def test_frequency_filter_refusals(dev, lib_path):
         C.frequency_filter(x.clone().requires_grad_(), resp)     # forward only
     with pytest.raises(RuntimeError):
         C.frequency_filter(x.cpu(), resp.cpu())                   # no CPU fallback
+
+
+def test_remove_above_fmax_matches_reference(dev, lib_path):
+    """tests/golden/core_fmax.npz holds the unmodified reference's output (pitches on both sides of Nyquist / 16)."""
+    from ddsp import core as C
+    g = _golden("core_fmax.npz")
+    got = C.remove_above_fmax(g["amps"].to(dev), g["pitch"].to(dev), SR / 2, level_start=1).cpu()
+    assert torch.equal(got, g["out"])
+    with pytest.raises(RuntimeError):
+        C.remove_above_fmax(g["amps"], g["pitch"], SR / 2)
