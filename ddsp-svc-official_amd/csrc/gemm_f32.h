@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(64 * NW) kernel(Args g, Epi epi) {
 // NW = 8 waves as a 4(M) x 2(N) grid, or NW = 4 as 2 x 2 (64x64 tiles: four times as many workgroups for the skinny
 // N = 256 layers, whose 128-row tilings leave a third of the CUs without work).
 template <int BM, int BN, class Epi, int NS = 3, int ABLATE = 0, int NW = 8, int A_MODE = A_PLAIN>  // ABLATE bit mask (timing experiments only): 1 no MFMA, 2 no DMA, 4 no epilogue stores, 8 no barrier
-__global__ void __launch_bounds__(64 * NW, (BM * BN <= 128 * 128 ? 4 : 2)) kernel_dma(Args g, Epi epi, int tiles_m, int tiles_n, int total_tiles) {
+__global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ? 4 : 2)) kernel_dma(Args g, Epi epi, int tiles_m, int tiles_n, int total_tiles) {
     constexpr int WGM = NW / 2, WGN = 2;
     constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
     constexpr int ROWS = BM + BN;            // rows per stage

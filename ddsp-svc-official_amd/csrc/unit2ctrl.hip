@@ -25,42 +25,38 @@ constexpr int DWK = 31;       // depthwise kernel
 
 // ---- weight preparation --------------------------------------------------------------------------
 // conv weight (Cout, Cin, 3) -> (Cout, 3*Cin) with k = tap*Cin + c  (matches gemm A_CONV3)
-__global__ void pack_conv3_kernel(const float* __restrict__ w, int Cout, int Cin, float* __restrict__ out) {
+__device__ __forceinline__ void pack_conv3_body(const float* __restrict__ w, int Cout, int Cin, float* __restrict__ out,
+                                                int vb, int vgrid) {   // vb / vgrid: block id / grid size of this job
     const int64_t total = (int64_t)Cout * Cin * 3;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)vb * 256 + threadIdx.x; i < total; i += (int64_t)vgrid * 256) {
         const int tap = (int)(i % 3);
         const int c = (int)((i / 3) % Cin);
         const int o = (int)(i / (3 * Cin));
         out[(int64_t)o * 3 * Cin + (int64_t)tap * Cin + c] = w[i];
     }
 }
+__global__ void __launch_bounds__(256) pack_conv3_kernel(const float* __restrict__ w, int Cout, int Cin, float* __restrict__ out) {
+    pack_conv3_body(w, Cout, Cin, out, blockIdx.x, gridDim.x);
+}
 
 // q/k/v projections as ONE GEMM: rows [q_w; k_w; v_w] (3*512 x 256) and the three biases behind each other
-__global__ void __launch_bounds__(256) pack_qkv_kernel(const float* __restrict__ qw, const float* __restrict__ kw,
-                                                       const float* __restrict__ vw, const float* __restrict__ qb,
-                                                       const float* __restrict__ kb, const float* __restrict__ vb,
-                                                       float* __restrict__ w, float* __restrict__ bias) {
+__device__ __forceinline__ void pack_qkv_body(const float* __restrict__ qw, const float* __restrict__ kw,
+                                              const float* __restrict__ vw, const float* __restrict__ qb,
+                                              const float* __restrict__ kb, const float* __restrict__ vb_,
+                                              float* __restrict__ w, float* __restrict__ bias, int vb, int vgrid) {
     const int n = INNER * D;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 3 * n; i += gridDim.x * blockDim.x) {
+    for (int i = vb * 256 + threadIdx.x; i < 3 * n; i += vgrid * 256) {
         const int which = i / n, j = i - which * n;
         w[i] = which == 0 ? qw[j] : (which == 1 ? kw[j] : vw[j]);
-        if (j < INNER) bias[which * INNER + j] = which == 0 ? qb[j] : (which == 1 ? kb[j] : vb[j]);
+        if (j < INNER) bias[which * INNER + j] = which == 0 ? qb[j] : (which == 1 ? kb[j] : vb_[j]);
     }
 }
 
 // pw1 (1024 x 256, rows 0..511 values, 512..1023 gates of the GLU, ddsp/pcmer.py conformer conv module) re-ordered
 // for the gated-pair GEMM epilogue: packed rows 64t..64t+31 = values, 64t+32..64t+63 = gates of channels 32t..32t+31.
-struct GluPackArgs {
-    const float* w[3];
-    const float* b[3];
-};
-__global__ void __launch_bounds__(256) pack_glu_kernel(GluPackArgs a, float* __restrict__ wp, float* __restrict__ bp) {
-    const int l = blockIdx.y;
-    const float* w = a.w[l];
-    const float* bias = a.b[l];
-    float* wo = wp + (size_t)l * 2 * INNER * D;
-    float* bo = bp + (size_t)l * 2 * INNER;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * INNER * (D / 4); i += gridDim.x * blockDim.x) {
+__device__ __forceinline__ void pack_glu_body(const float* __restrict__ w, const float* __restrict__ bias,
+                                              float* __restrict__ wo, float* __restrict__ bo, int vb, int vgrid) {
+    for (int i = vb * 256 + threadIdx.x; i < 2 * INNER * (D / 4); i += vgrid * 256) {
         const int p = i / (D / 4), k4 = (i % (D / 4)) * 4;
         const int t = p >> 6, within = p & 63;
         const int src = within < 32 ? 32 * t + within : INNER + 32 * t + (within - 32);
@@ -94,10 +90,10 @@ struct EpiSplit3 {  // column block n / 512 selects the destination matrix (q, k
 };
 
 // W[o][:] = g[o] * v[o][:] / ||v[o]||_2   (old-style weight_norm, ddsp/unit2control.py:61); one wave per row
-__global__ void __launch_bounds__(256) weight_norm_kernel(const float* __restrict__ g, const float* __restrict__ v,
-                                                          int n_out, int n_in, float* __restrict__ w) {
+__device__ __forceinline__ void weight_norm_body(const float* __restrict__ g, const float* __restrict__ v, int n_out,
+                                                 int n_in, float* __restrict__ w, int vb) {
     const int lane = threadIdx.x & 63;
-    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int o = vb * 4 + (threadIdx.x >> 6);
     if (o >= n_out) return;
     const float* row = v + (int64_t)o * n_in;
     float ss = 0.f;
@@ -105,6 +101,40 @@ __global__ void __launch_bounds__(256) weight_norm_kernel(const float* __restric
     ss = wave_sum(ss);
     const float scale = g[o] / sqrtf(ss);
     for (int i = lane; i < n_in; i += 64) w[(int64_t)o * n_in + i] = row[i] * scale;
+}
+__global__ void __launch_bounds__(256) weight_norm_kernel(const float* __restrict__ g, const float* __restrict__ v,
+                                                          int n_out, int n_in, float* __restrict__ w) {
+    weight_norm_body(g, v, n_out, n_in, w, blockIdx.x);
+}
+
+// All weight preparation of one forward in ONE launch (it used to be 6-7: two conv packs, the head's weight norm,
+// three QKV packs, the GLU re-ordering): the jobs are independent, each gets a range of blocks.  The weights arrive
+// as raw pointers on every call, so they are re-prepared every call; what can be saved is the launches.
+struct PrepArgs {
+    ddsp_u2c_weights w;
+    float *w1, *w2, *wh, *wqkv, *bqkv, *wglu, *bglu;
+    int end[5];          // one past the last block of: conv1 | conv2 | head | qkv (3 layers) | glu (3 layers, may be empty)
+    int qkv_blocks, glu_blocks;   // blocks per layer
+};
+__global__ void __launch_bounds__(256) u2c_prepare_kernel(PrepArgs a) {
+    const int b = blockIdx.x;
+    if (b < a.end[0]) {
+        pack_conv3_body(a.w.prenet_conv1_w, D, a.w.n_unit, a.w1, b, a.end[0]);
+    } else if (b < a.end[1]) {
+        pack_conv3_body(a.w.prenet_conv2_w, D, D, a.w2, b - a.end[0], a.end[1] - a.end[0]);
+    } else if (b < a.end[2]) {
+        weight_norm_body(a.w.head_g, a.w.head_v, a.w.n_out, D, a.wh, b - a.end[1]);
+    } else if (b < a.end[3]) {
+        const int r = b - a.end[2], l = r / a.qkv_blocks;
+        const ddsp_u2c_layer& L = a.w.layer[l];
+        pack_qkv_body(L.q_w, L.k_w, L.v_w, L.q_b, L.k_b, L.v_b, a.wqkv + (size_t)l * 3 * INNER * D,
+                      a.bqkv + (size_t)l * 3 * INNER, r - l * a.qkv_blocks, a.qkv_blocks);
+    } else {
+        const int r = b - a.end[3], l = r / a.glu_blocks;
+        const ddsp_u2c_layer& L = a.w.layer[l];
+        pack_glu_body(L.cm_pw1_w, L.cm_pw1_b, a.wglu + (size_t)l * 2 * INNER * D, a.bglu + (size_t)l * 2 * INNER,
+                      r - l * a.glu_blocks, a.glu_blocks);
+    }
 }
 
 // ---- GroupNorm(4, 256) over (64 channels x all frames) per utterance + LeakyReLU -------------------
@@ -861,28 +891,31 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
     const size_t n_w1 = (size_t)D * 3 * w.n_unit, n_w2 = (size_t)D * 3 * D, n_wh = (size_t)w.n_out * D;
     const float* zero_page = nullptr;   // source of the conv taps that fall off an utterance (LDS-DMA conv GEMM)
     if (int rc = ddsp_zero_page(ctx, &zero_page)) return rc;
-    PROF(PF_U2C_PREP, 0, 8.0 * (n_w1 + n_w2 + n_wh),
-         hipLaunchKernelGGL(pack_conv3_kernel, dim3(grid_for(n_w1)), dim3(256), 0, st, w.prenet_conv1_w, D, w.n_unit, bf.w1);
-         hipLaunchKernelGGL(pack_conv3_kernel, dim3(grid_for(n_w2)), dim3(256), 0, st, w.prenet_conv2_w, D, D, bf.w2);
-         hipLaunchKernelGGL(weight_norm_kernel, dim3((w.n_out + 3) / 4), dim3(256), 0, st, w.head_g, w.head_v, w.n_out, D, bf.wh);
-         for (int l = 0; l < 3; ++l)
-             hipLaunchKernelGGL(pack_qkv_kernel, dim3(512), dim3(256), 0, st, w.layer[l].q_w, w.layer[l].k_w, w.layer[l].v_w,
-                                w.layer[l].q_b, w.layer[l].k_b, w.layer[l].v_b, bf.wqkv + (size_t)l * 3 * INNER * D,
-                                bf.bqkv + (size_t)l * 3 * INNER));
     // Inference, and enough rows that the Linear layers run the 128x128 DMA tile anyway: GLU is formed inside the pw1
     // GEMM (half the store, no glu kernel).  Training keeps pw1's raw output for the backward pass; small batches keep
     // the tile shapes that suit them and the separate glu kernel.
     bool fuse_glu = !bf.l[0].pre && (int64_t)((M + 127) / 128) * (2 * INNER / 128) >= 512;
     for (int l = 0; l < 3; ++l)
         fuse_glu = fuse_glu && ((uintptr_t)w.layer[l].cm_pw1_w % 16) == 0;
-    if (fuse_glu) {
-        GluPackArgs ga;
-        for (int l = 0; l < 3; ++l) {
-            ga.w[l] = w.layer[l].cm_pw1_w;
-            ga.b[l] = w.layer[l].cm_pw1_b;
-        }
-        PROF(PF_U2C_PREP, 0, 8.0 * 3 * 2 * INNER * D,
-             hipLaunchKernelGGL(pack_glu_kernel, dim3(128, 3), dim3(256), 0, st, ga, bf.wglu, bf.bglu));
+    {   // weight preparation, one launch (u2c_prepare_kernel)
+        PrepArgs pa;
+        pa.w = w;
+        pa.w1 = bf.w1;
+        pa.w2 = bf.w2;
+        pa.wh = bf.wh;
+        pa.wqkv = bf.wqkv;
+        pa.bqkv = bf.bqkv;
+        pa.wglu = bf.wglu;
+        pa.bglu = bf.bglu;
+        pa.qkv_blocks = 256;
+        pa.glu_blocks = 128;
+        pa.end[0] = (int)grid_for((int64_t)n_w1, 256, 512);
+        pa.end[1] = pa.end[0] + (int)grid_for((int64_t)n_w2, 256, 512);
+        pa.end[2] = pa.end[1] + (w.n_out + 3) / 4;
+        pa.end[3] = pa.end[2] + 3 * pa.qkv_blocks;
+        pa.end[4] = pa.end[3] + (fuse_glu ? 3 * pa.glu_blocks : 0);
+        PROF(PF_U2C_PREP, 0, 8.0 * (n_w1 + n_w2 + n_wh + 3.0 * 3 * INNER * D + (fuse_glu ? 3.0 * 2 * INNER * D : 0.0)),
+             hipLaunchKernelGGL(u2c_prepare_kernel, dim3((unsigned)pa.end[4]), dim3(256), 0, st, pa));
     }
     // ---- prenet: conv k3 -> GroupNorm(4) -> LeakyReLU -> conv k3 ----
     {
