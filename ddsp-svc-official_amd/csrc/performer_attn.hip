@@ -101,10 +101,11 @@ __global__ void __launch_bounds__(256, 4) performer_kv_kernel(const float* __res
     const float* kb = k + ((int64_t)b * Fr) * INNER + h * DH;     // wave-uniform bases, 32-bit lane offsets
     const float* vb = v + ((int64_t)b * Fr) * INNER + h * DH;
     const int last = Fr - 1;
-    float ka[16];
-    load_quarter_row(kb + (c < Fr ? c : last) * INNER + 16 * g, ka);
-#pragma unroll 2
-    for (int ft = 0; ft < n_ft; ++ft) {
+    // One frame tile.  `cur` holds its k rows, `nxt` receives the next tile's: the two buffers swap roles from tile to
+    // tile (loop unrolled by two below).  A copy `ka = kn` at the end of the tile looks harmless but the compiler
+    // spreads its v_movs through the FIRST product, which then waits for rows loaded a few MFMAs earlier - the
+    // prefetch is gone and every tile pays an L2 round trip.
+    auto tile = [&](int ft, const float (&cur)[16], float (&nxt)[16]) {
         // v operand of the second product: frames 4g+t (t = k-step); output block et covers channels 4c + et, so
         // that the four blocks of a lane are ONE 16-byte load per frame
         f32x4_t vv[4];
@@ -114,22 +115,22 @@ __global__ void __launch_bounds__(256, 4) performer_kv_kernel(const float* __res
             f = f < Fr ? f : last;
             vv[t] = *(const f32x4_t*)(vb + f * INNER + 4 * c);
         }
-        // next tile's k rows (used only after this tile's products)
-        float kn[16];
+        // next tile's k rows (used only in the next call)
         int nf = 16 * (ft + 1) + c;
         nf = nf < Fr ? nf : last;
-        load_quarter_row(kb + nf * INNER + 16 * g, kn);
+        load_quarter_row(kb + nf * INNER + 16 * g, nxt);
+        // all eight loads of the tile are issued HERE, a whole product ahead of their first use
+        __builtin_amdgcn_sched_barrier(0);
         float ss = 0.f;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) ss = fmaf(ka[s], ka[s], ss);
-        // two independent accumulator chains (even / odd k-steps), summed afterwards: a 16x16x4 MFMA that accumulates
-        // onto the previous one's result cannot issue until that result is written
+        for (int s = 0; s < 16; ++s) ss = fmaf(cur[s], cur[s], ss);
+        // two independent accumulator chains (even / odd k-steps), summed afterwards
         f32x4_t S = ft == n_ft - 1 ? c_last : c_full;
         f32x4_t S2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 16; s += 2) {
-            S = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[s], pb[s], S, 0, 0, 0);
-            S2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[s + 1], pb[s + 1], S2, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[s], pb[s], S, 0, 0, 0);
+            S2 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[s + 1], pb[s + 1], S2, 0, 0, 0);
         }
         S2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ss, NEG_HALF, S2, 0, 0, 0);
         S += S2;
@@ -142,8 +143,13 @@ __global__ void __launch_bounds__(256, 4) performer_kv_kernel(const float* __res
 #pragma unroll
             for (int et = 0; et < 4; ++et)
                 acc[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t], vv[t][et], acc[et], 0, 0, 0);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) ka[s] = kn[s];
+    };
+    float ka[16], kc[16];
+    load_quarter_row(kb + (c < Fr ? c : last) * INNER + 16 * g, ka);
+#pragma unroll 1
+    for (int ft = 0; ft < n_ft; ft += 2) {
+        tile(ft, ka, kc);
+        if (ft + 1 < n_ft) tile(ft + 1, kc, ka);
     }
     float* kr = ks + (int64_t)bh * KST;
     const float ksum = group_sum((ksum4[0] + ksum4[1]) + (ksum4[2] + ksum4[3]));
@@ -219,6 +225,7 @@ __global__ void __launch_bounds__(256, 4) performer_q_kernel(const float* __rest
         int jn = 16 * (jt + 1) + c;
         jn = jn < NF ? jn : NF - 1;
         load_quarter_row(P + jn * DH + 16 * g, pn);
+        __builtin_amdgcn_sched_barrier(0);           // loads first, see the K kernel
         f32x4_t S = jt == NJT - 1 ? c_last : f32x4_t{0.f, 0.f, 0.f, 0.f};
         f32x4_t S2 = {0.f, 0.f, 0.f, 0.f};           // (two independent chains, see the K kernel)
 #pragma unroll
