@@ -207,6 +207,10 @@ def main():
         out["kernel_families_ms_per_step"] = {k: round(v["ms_total"] / nb, 4) for k, v in fam.items()}
         out["kernel_families_tflops"] = {k: round(v["flops_total"] / (v["ms_total"] * 1e-3) / 1e12, 2)
                                          for k, v in fam.items() if v["flops_total"] > 0}
+        # algorithmic bytes (what each launch must read + write once) over the family's event time: the figure to hold
+        # against the 8 TB/s HBM roofline for the families that are HBM-bound (scan, activations, row kernels, prep)
+        out["kernel_families_gbps_algorithmic"] = {k: round(v["bytes_total"] / (v["ms_total"] * 1e-3) / 1e9, 1)
+                                                   for k, v in fam.items() if v["bytes_total"] > 0 and v["ms_total"] > 0}
         if world == 1 and not args.no_cpu_baseline and args.mode == "synth":
             out["cpu_baseline"] = cpu_baseline(seed)
         print(json.dumps(out), flush=True)
