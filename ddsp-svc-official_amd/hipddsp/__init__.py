@@ -149,8 +149,16 @@ class Context:
         raise RuntimeError(f"{what} failed ({rc}): {msg}")
 
     def call(self, name, *args):
+        if getattr(self, "_frozen", False):
+            raise RuntimeError("this ddsp context belongs to a captured HIP graph (its scratch arena and tables are "
+                               "referenced by the graph's kernels); use another context for eager calls")
         rc = getattr(self.lib, name)(self.handle, self._stream(), *args)
         self._check(rc, name)
+
+    def freeze(self):
+        """After a HIP graph has captured calls made through this context: refuse every further eager call, so that
+        nothing can regrow or overwrite the scratch memory the captured kernels point into."""
+        self._frozen = True
 
     # -- measurement ---------------------------------------------------------------------------
     def profile_begin(self, families=None):
@@ -386,10 +394,33 @@ _contexts = {}
 _ctx_lock = threading.Lock()
 
 
+_override = threading.local()
+
+
+class use_context:
+    """`with use_context(ctx):` makes `context_for` return `ctx` on this thread for that device - how a graph-capturing
+    caller routes a model's library calls through a context of its own (graphed.GraphedSynth)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        self.prev = getattr(_override, "ctx", None)
+        _override.ctx = self.ctx
+        return self.ctx
+
+    def __exit__(self, *exc):
+        _override.ctx = self.prev
+        return False
+
+
 def context_for(device):
     """Per (device, thread) context cache (one handle per stream/thread)."""
     dev = torch.device(device)
     idx = dev.index if dev.index is not None else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    forced = getattr(_override, "ctx", None)
+    if forced is not None and dev.type == "cuda" and forced.device.index == idx:
+        return forced
     key = (dev.type, idx, threading.get_ident())
     with _ctx_lock:
         ctx = _contexts.get(key)

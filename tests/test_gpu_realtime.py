@@ -103,3 +103,39 @@ def test_offline_render_plumbing(dev, lib_path):
     assert sr_o == 44100 and got.shape == result.shape
     assert np.sqrt(np.mean((got - result) ** 2)) < 1e-4
     assert np.abs(got[64 * 512:70 * 512]).max() == 0.0    # 9-frame dilation: frames 64..70 of the 60..74 stretch are closed
+
+
+def test_graphed_forward_equals_eager(dev, lib_path):
+    """graphed.GraphedSynth (HIP-graph replay of the inference forward on a context of its own) against the eager
+    call: same inputs and the same injected noise give the same bits, across several replays with new inputs, after
+    an in-place weight update, and the captured context refuses eager use."""
+    import synthetic, graphed
+    model, cfg = synthetic.build_model("CombSub", seed=11, device=dev)
+    model.eval()
+    B, Fr = 1, 87
+    g = graphed.GraphedSynth(model, B, Fr)
+    T = Fr * 512
+    for rep in range(3):
+        inp = {k: v.to(dev) for k, v in synthetic.make_inputs(500 + rep, B, Fr, with_noise=False).items()}
+        noise = torch.rand(B, T, device=dev, generator=torch.Generator(device=dev).manual_seed(rep))
+        with torch.no_grad():
+            want = model(inp["units"], inp["f0"], inp["volume"], inp["spk_id"], noise=noise)
+        got = g(inp["units"], inp["f0"], inp["volume"], inp["spk_id"], noise=noise)
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+        assert torch.equal(got[2][0], want[2][0]) and torch.equal(got[2][1], want[2][1])
+        assert float(want[0].abs().max()) > 0
+    # fresh noise per replay when none is injected: two replays of the same inputs differ in the noise branch only
+    a = [t.clone() for t in (g(inp["units"], inp["f0"], inp["volume"], inp["spk_id"])[2])]
+    b = g(inp["units"], inp["f0"], inp["volume"], inp["spk_id"])[2]
+    assert torch.equal(a[0], b[0]) and not torch.equal(a[1], b[1])
+    # weights are read at replay time
+    with torch.no_grad():
+        list(model.unit2ctrl.parameters())[-1].add_(0.05)
+        want = model(inp["units"], inp["f0"], inp["volume"], inp["spk_id"], noise=noise)
+    got = g(inp["units"], inp["f0"], inp["volume"], inp["spk_id"], noise=noise)
+    assert torch.equal(got[0], want[0])
+    with pytest.raises(RuntimeError):
+        g.ctx.upsample(torch.zeros(1, 2, 1, device=dev), 512)       # frozen: owned by the graph
+    with pytest.raises(ValueError):
+        g(inp["units"][:, :5], inp["f0"][:, :5], inp["volume"][:, :5], inp["spk_id"])

@@ -10,6 +10,17 @@ dev = torch.device("cuda:0")
 ctx = hipddsp.context_for(dev)
 out = {}
 
+def host_ms(fn, n=50):
+    """Host time to ENQUEUE one call (GPU idle at the start, no synchronisation inside the loop)."""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    return (t1 - t0) / n * 1e3
+
+
 def timeit(fn, n=20, warm=3):
     for _ in range(warm):
         fn()
@@ -46,7 +57,19 @@ def rt():
         ctx.volume_gate_(sig, inp["volume"], -60, 512)
         return sp.push(sig[0])
 t = timeit(rt, n=50, warm=5)
-out["realtime_block_B1"] = {"ms_per_block": t * 1e3, "block_ms_of_audio": 200.0, "x_realtime": 0.2 / t}
+out["realtime_block_B1"] = {"ms_per_block": t * 1e3, "block_ms_of_audio": 200.0, "x_realtime": 0.2 / t,
+                            "host_enqueue_ms": host_ms(rt)}
+
+# the same block with the model forward replayed from a HIP graph (graphed.GraphedSynth); gate and SOLA stay eager
+import graphed
+gs = graphed.GraphedSynth(model, 1, 87)
+def rt_graph():
+    sig = gs(inp["units"], inp["f0"], inp["volume"], inp["spk_id"])[0]
+    ctx.volume_gate_(sig, inp["volume"], -60, 512)
+    return sp.push(sig[0])
+t = timeit(rt_graph, n=50, warm=5)
+out["realtime_block_B1_hip_graph"] = {"ms_per_block": t * 1e3, "block_ms_of_audio": 200.0, "x_realtime": 0.2 / t,
+                                      "host_enqueue_ms": host_ms(rt_graph)}
 # (the model constructors print a banner line each; the JSON goes to its own file when a path is given)
 if len(sys.argv) > 1:
     json.dump(out, open(sys.argv[1], "w"), indent=1)
