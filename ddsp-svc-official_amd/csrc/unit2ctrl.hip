@@ -112,8 +112,8 @@ __global__ void __launch_bounds__(256) weight_norm_kernel(const float* __restric
 // as raw pointers on every call, so they are re-prepared every call; what can be saved is the launches.
 struct PrepArgs {
     ddsp_u2c_weights w;
-    float *w1, *w2, *wh, *wqkv, *bqkv, *wglu, *bglu;
-    int end[5];          // one past the last block of: conv1 | conv2 | head | qkv (3 layers) | glu (3 layers, may be empty)
+    float *w1, *w2, *wh, *wqkv, *bqkv, *wglu, *bglu, *wdw;
+    int end[6];          // one past the last block of: conv1 | conv2 | head | qkv (3 layers) | glu (3 layers, may be empty) | dw taps
     int qkv_blocks, glu_blocks;   // blocks per layer
 };
 __global__ void __launch_bounds__(256) u2c_prepare_kernel(PrepArgs a) {
@@ -129,11 +129,18 @@ __global__ void __launch_bounds__(256) u2c_prepare_kernel(PrepArgs a) {
         const ddsp_u2c_layer& L = a.w.layer[l];
         pack_qkv_body(L.q_w, L.k_w, L.v_w, L.q_b, L.k_b, L.v_b, a.wqkv + (size_t)l * 3 * INNER * D,
                       a.bqkv + (size_t)l * 3 * INNER, r - l * a.qkv_blocks, a.qkv_blocks);
-    } else {
+    } else if (b < a.end[4]) {
         const int r = b - a.end[3], l = r / a.glu_blocks;
         const ddsp_u2c_layer& L = a.w.layer[l];
         pack_glu_body(L.cm_pw1_w, L.cm_pw1_b, a.wglu + (size_t)l * 2 * INNER * D, a.bglu + (size_t)l * 2 * INNER,
                       r - l * a.glu_blocks, a.glu_blocks);
+    } else {
+        // depthwise taps (512, 1, 31) -> [tap][channel], all three layers: 3 * 31 * 512 elements
+        for (int i = (b - a.end[4]) * 256 + threadIdx.x; i < 3 * DWK * INNER; i += (a.end[5] - a.end[4]) * 256) {
+            const int l = i / (DWK * INNER), r = i - l * DWK * INNER;
+            const int t = r / INNER, c = r - t * INNER;
+            a.wdw[i] = a.w.layer[l].cm_dw_w[c * DWK + t];
+        }
     }
 }
 
@@ -366,21 +373,24 @@ __global__ void __launch_bounds__(256) glu_kernel(const float* __restrict__ g1, 
 
 // depthwise Conv1d(k=31, pad 15, groups=512) over frames + SiLU; weight (512,1,31).
 // One thread owns one channel for a run of DW_RUN consecutive frames of one utterance: its 31 taps and a
-// sliding window of DW_RUN+30 inputs stay in registers (2.9 loads per output instead of 31); lanes walk
-// channels, so every load/store of a wavefront is one contiguous 256-B row segment.
-constexpr int DW_RUN = 16;
+// sliding window of DW_RUN+30 inputs stay in registers (1.9 loads per output instead of 31); lanes walk
+// channels, so every load/store of a wavefront is one contiguous 256-B row segment.  The taps are addressed as
+// w[c*wsc + t*wst]: the forward pass reads a copy laid out [tap][channel] (wsc = 1, wst = 512; made by the weight
+// preparation launch) so that the 31 tap loads are contiguous rows too - in the (512, 31) parameter layout every
+// tap load of a wavefront touches 64 cache lines, which cost more than the convolution itself.
+constexpr int DW_RUN = 32;
 // SILU: apply SiLU (forward) and optionally keep the pre-activation; FLIP: correlate with reversed taps and no
 // bias (the input-gradient of the same convolution).
 template <bool SILU, bool FLIP>
 __global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, int B, int Fr,
-                                                     float* __restrict__ out, float* __restrict__ pre) {
+                                                     float* __restrict__ out, float* __restrict__ pre, int wsc, int wst) {
     const int c = blockIdx.x * 256 + threadIdx.x;       // channel (INNER = 512 -> 2 blocks in x)
     const int runs = (Fr + DW_RUN - 1) / DW_RUN;
     const int b = blockIdx.y / runs, f0 = (blockIdx.y % runs) * DW_RUN;
     float wt[DWK];
 #pragma unroll
-    for (int t = 0; t < DWK; ++t) wt[t] = w[c * DWK + (FLIP ? DWK - 1 - t : t)];
+    for (int t = 0; t < DWK; ++t) wt[t] = w[c * wsc + (FLIP ? DWK - 1 - t : t) * wst];
     const float* xb = x + ((int64_t)b * Fr) * INNER + c;
     float win[DW_RUN + DWK - 1];
 #pragma unroll
@@ -824,7 +834,7 @@ struct LayerBufs {
     float *x_in, *y, *q, *k, *v, *qf, *kf, *ks, *cx, *dinv, *attn, *x_mid, *y2, *g1, *glu, *pre, *dwo, *x_out;
 };
 struct U2CBufs {
-    float *w1, *w2, *wh, *wqkv, *bqkv, *wglu, *bglu, *t1, *t2, *gst, *y_final;
+    float *w1, *w2, *wh, *wqkv, *bqkv, *wglu, *bglu, *wdw, *t1, *t2, *gst, *y_final;
     LayerBufs l[3];
 };
 
@@ -855,6 +865,7 @@ static void plan_forward(Arena& a, U2CBufs& bf, const ddsp_u2c_weights& w, int64
     bf.bqkv = a.get((size_t)3 * 3 * INNER);
     bf.wglu = a.get((size_t)3 * 2 * INNER * D);    // pw1 re-ordered for the fused GLU epilogue (inference)
     bf.bglu = a.get((size_t)3 * 2 * INNER);
+    bf.wdw = a.get((size_t)3 * DWK * INNER);         // depthwise taps as [tap][channel]
     bf.t1 = a.get(M * D);
     bf.t2 = a.get(M * D);
     bf.gst = a.get((size_t)B * 4 * 2);
@@ -937,8 +948,10 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         pa.end[2] = pa.end[1] + (w.n_out + 3) / 4;
         pa.end[3] = pa.end[2] + 3 * pa.qkv_blocks;
         pa.end[4] = pa.end[3] + (fuse_glu ? 3 * pa.glu_blocks : 0);
+        pa.end[5] = pa.end[4] + 48;
+        pa.wdw = bf.wdw;
         PROF(PF_U2C_PREP, 0, 8.0 * (n_w1 + n_w2 + n_wh + 3.0 * 3 * INNER * D + (fuse_glu ? 3.0 * 2 * INNER * D : 0.0)),
-             hipLaunchKernelGGL(u2c_prepare_kernel, dim3((unsigned)pa.end[4]), dim3(256), 0, st, pa));
+             hipLaunchKernelGGL(u2c_prepare_kernel, dim3((unsigned)pa.end[5]), dim3(256), 0, st, pa));
     }
     // ---- prenet: conv k3 -> GroupNorm(4) -> LeakyReLU -> conv k3 ----
     {
@@ -1057,7 +1070,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         }
         PROF(PF_U2C_ROWWISE, 2.0 * M * INNER * DWK, 8.0 * M * INNER,
              hipLaunchKernelGGL((dwconv_kernel<true, false>), dim3(INNER / 256, (unsigned)(B * ((Fr + DW_RUN - 1) / DW_RUN))),
-                                dim3(256), 0, st, b.glu, L.cm_dw_w, L.cm_dw_b, (int)B, (int)Fr, b.dwo, b.pre));
+                                dim3(256), 0, st, b.glu, bf.wdw + (size_t)l * DWK * INNER, L.cm_dw_b, (int)B, (int)Fr, b.dwo, b.pre, 1, INNER));
         {
             gemm::Args g = gemm::make(b.dwo, INNER, L.cm_pw2_w, INNER, iM, D, INNER);
             gemm::EpiResidual e{b.x_out, b.x_mid, D, L.cm_pw2_b};
@@ -1287,7 +1300,7 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
                            (int64_t)INNER * DWK, GLP(cm_dw_w));
         if ((rc = colsum(ctx, st, dB512, INNER, M, INNER, nullptr, 0, cpart, GLP(cm_dw_b)))) return rc;
         hipLaunchKernelGGL((dwconv_kernel<false, true>), dim3(INNER / 256, (unsigned)(B * ((Fr + DW_RUN - 1) / DW_RUN))),
-                           dim3(256), 0, st, dB512, L.cm_dw_w, nullptr, (int)B, (int)Fr, dC512, nullptr);   // d_glu
+                           dim3(256), 0, st, dB512, L.cm_dw_w, nullptr, (int)B, (int)Fr, dC512, nullptr, DWK, 1);   // d_glu
         hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for(M * INNER)), dim3(256), 0, st, b.g1, dC512, M, dG1);
         if ((rc = wgrad(ctx, st, dG1, 2 * INNER, 2 * INNER, b.y2, D, D, M, wpart, GLP(cm_pw1_w), D, 0))) return rc;
         if ((rc = colsum(ctx, st, dG1, 2 * INNER, M, 2 * INNER, nullptr, 0, cpart, GLP(cm_pw1_b)))) return rc;
