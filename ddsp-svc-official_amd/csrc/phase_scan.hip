@@ -71,7 +71,11 @@ struct ScanOut {
     float* phase_frames;
 };
 
-template <bool PRECISE>
+// VEC8: hop == 512 and 16-byte aligned outputs - a lane owns exactly 8 consecutive samples = 32 contiguous bytes per
+// output array, which leave as two 16-byte stores.  (As dword stores each instruction scattered 64 x 4 bytes at a
+// 32-byte stride over 16 cache lines and the kernel was store-issue-bound at 0.65 TB/s.)  The arithmetic per sample
+// is the same in both instantiations.
+template <bool PRECISE, bool VEC8 = false>
 __global__ void __launch_bounds__(256) frame_scan_kernel(const float* __restrict__ f0_frames,
                                                          const double* __restrict__ frame_sum,
                                                          const float* __restrict__ initial_phase,
@@ -92,12 +96,13 @@ __global__ void __launch_bounds__(256) frame_scan_kernel(const float* __restrict
     for (int i = lane; i < m; i += 64) before += frame_sum[b * Fr + i];
     before = wave_sum_d(before);
 
-    const int per_lane = (hop + 63) / 64;  // host guarantees per_lane <= 16
-    float fval[16];
-    double local[16];
+    constexpr int NL = VEC8 ? 8 : 16;
+    const int per_lane = VEC8 ? 8 : (hop + 63) / 64;  // host guarantees per_lane <= 16
+    float fval[NL];
+    double local[NL];
     double run = 0.0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NL; ++i) {
         if (i < per_lane) {
             int j = lane * per_lane + i;
             float f = 0.f;
@@ -127,8 +132,9 @@ __global__ void __launch_bounds__(256) frame_scan_kernel(const float* __restrict
     const float pi_f = 3.14159274101257324f;
     const int64_t t0 = fidx * (int64_t)hop;
 
+    float r_v[VEC8 ? 8 : 1], ph_v[VEC8 ? 8 : 1], c_v[VEC8 ? 8 : 1];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NL; ++i) {
         if (i < per_lane) {
             int j = lane * per_lane + i;
             if (j < hop) {
@@ -143,20 +149,39 @@ __global__ void __launch_bounds__(256) frame_scan_kernel(const float* __restrict
                     r = Sf - rintf(Sf);
                 }
                 const int64_t t = t0 + j;
-                if (out.rot) out.rot[t] = r;
                 const float ph = __fmul_rn(two_pi_f, r);
-                if (out.phase) out.phase[t] = ph;
                 if (j == 0) out.phase_frames[fidx] = ph;
-                if (out.f0_up) out.f0_up[t] = fval[i];
+                float c = 0.f;
                 if (out.comb) {
                     float x = __fdiv_rn(__fmul_rn(srf, r), __fadd_rn(fval[i], 1e-3f));
                     float p = __fmul_rn(pi_f, x);
-                    float c = (x == 0.0f) ? 1.0f : __fdiv_rn(sinf(p), p);
+                    c = (x == 0.0f) ? 1.0f : __fdiv_rn(sinf(p), p);
                     if (comb_mode == DDSP_COMB_SINC_GATED && fval[i] <= 0.0f) c = 0.0f;
-                    out.comb[t] = c;
+                }
+                if constexpr (VEC8) {
+                    r_v[i] = r;
+                    ph_v[i] = ph;
+                    c_v[i] = c;
+                } else {
+                    if (out.rot) out.rot[t] = r;
+                    if (out.phase) out.phase[t] = ph;
+                    if (out.f0_up) out.f0_up[t] = fval[i];
+                    if (out.comb) out.comb[t] = c;
                 }
             }
         }
+    }
+    if constexpr (VEC8) {
+        auto put = [&](float* dst, const float (&v)[8]) {
+            if (!dst) return;
+            float* q = dst + t0 + lane * 8;
+            *(f32x4*)q = f32x4{v[0], v[1], v[2], v[3]};
+            *(f32x4*)(q + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        };
+        put(out.rot, r_v);
+        put(out.phase, ph_v);
+        put(out.f0_up, fval);
+        put(out.comb, c_v);
     }
 }
 
@@ -218,17 +243,20 @@ extern "C" int ddsp_phase_scan(ddsp_ctx* ctx, void* stream, const float* f0_fram
     const unsigned blocks = (unsigned)ceil_div64(nf, WAVES_PER_BLOCK);
     ScanOut o{rot, phase, comb, f0_up, phase_frames};
     ddsp_prof_begin(ctx, st, PF_PHASE_SCAN);
+    const bool vec8 = hop == 512 && (((uintptr_t)rot | (uintptr_t)phase | (uintptr_t)comb | (uintptr_t)f0_up) % 16) == 0;
+#define DDSP_SCAN(P, V)                                                                                              \
+    hipLaunchKernelGGL((frame_scan_kernel<P, V>), dim3(blocks), dim3(256), 0, st, f0_frames, fsum, initial_phase, nf, \
+                       (int)Fr, hop, scale, sr, comb_mode, o)
     if (precise) {
         hipLaunchKernelGGL(frame_sum_kernel<true>, dim3(blocks), dim3(256), 0, st, f0_frames, nf, (int)Fr, hop, scale,
                            sr, fsum);
-        hipLaunchKernelGGL(frame_scan_kernel<true>, dim3(blocks), dim3(256), 0, st, f0_frames, fsum, initial_phase, nf,
-                           (int)Fr, hop, scale, sr, comb_mode, o);
+        if (vec8) DDSP_SCAN(true, true); else DDSP_SCAN(true, false);
     } else {
         hipLaunchKernelGGL(frame_sum_kernel<false>, dim3(blocks), dim3(256), 0, st, f0_frames, nf, (int)Fr, hop, scale,
                            sr, fsum);
-        hipLaunchKernelGGL(frame_scan_kernel<false>, dim3(blocks), dim3(256), 0, st, f0_frames, fsum, initial_phase,
-                           nf, (int)Fr, hop, scale, sr, comb_mode, o);
+        if (vec8) DDSP_SCAN(false, true); else DDSP_SCAN(false, false);
     }
+#undef DDSP_SCAN
     {
         const double outs = (rot ? 1 : 0) + (phase ? 1 : 0) + (comb ? 1 : 0) + (f0_up ? 1 : 0);
         ddsp_prof_end(ctx, st, 0.0, 4.0 * nf * (2.0 + outs * hop));
