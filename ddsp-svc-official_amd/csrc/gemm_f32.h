@@ -601,6 +601,11 @@ inline void launch(hipStream_t st, const Args& g, int batch, const Epi& epi) {
         }
     }
     if constexpr (A_KC && B_KC && A_MODE == A_PLAIN) {
+        if (dma_ok(g) && g.N <= 256 && blocks(64, 64) >= 256) {
+            // skinny layers also at half the bench batch (training, B = 32: 5504 rows -> 344 tiles of 64x64)
+            launch_dma<64, 64, Epi, 3, 0, 4>(st, g, batch, epi);
+            return;
+        }
         if (dma_ok(g) && blocks(128, 64) >= 256) {
             // 128x128 tiles (32 FLOP per staged byte, 2-stage ring, 2 workgroups per CU) when they still fill the
             // 512 resident slots; else 128x64
