@@ -247,3 +247,28 @@ def test_empty_batch_and_wide_units(dev, lib_path):
         d = _to(inp, dev)
         got = wide.to(dev)(d["units"], d["f0"], d["volume"], d["spk_id"], noise=d["noise"])[0]
     assert rms(got.cpu() - want) < GATE
+
+
+@pytest.mark.parametrize("name", ["CombSub", "Sins", "CombSubFast"])
+def test_full_bench_batch_equals_its_shards(dev, lib_path, name):
+    """Size-independent property at the bench size (BASELINE configs[1]: 64 clips x 172 frames): every utterance is
+    independent, so rendering the whole batch and rendering it in shards of 8 (what `--gpus 8` does, and small enough
+    to take the small-batch kernel choices: register-staged convs, separate GLU kernel, 128x64 / 64x64 tiles) must
+    give the same audio.  Also: the same call twice gives the same bits (no atomics, fixed reduction orders)."""
+    model, cfg = synthetic.build_model(name, seed=5, device=dev)
+    model.eval()
+    B, Fr = 64, 172
+    inp = {k: v.to(dev) for k, v in synthetic.make_inputs(900, B, Fr, with_noise=False).items()}
+    noise = torch.rand(B, Fr * 512, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    with torch.no_grad():
+        full = model(inp["units"], inp["f0"], inp["volume"], inp["spk_id"], noise=noise)[0]
+        again = model(inp["units"], inp["f0"], inp["volume"], inp["spk_id"], noise=noise)[0]
+        assert torch.equal(full, again)
+        scale = max(1e-3, rms(full))
+        for lo in range(0, B, 8):
+            sl = slice(lo, lo + 8)
+            part = model(inp["units"][sl], inp["f0"][sl], inp["volume"][sl], inp["spk_id"][sl], noise=noise[sl])[0]
+            assert part.shape == (8, Fr * 512)
+            err = rms(part - full[sl])
+            assert err < 2e-5 * scale, (name, lo, err, scale)
+    assert float(full.abs().max()) > 0 and torch.isfinite(full).all()
