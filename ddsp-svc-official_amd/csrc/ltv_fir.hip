@@ -120,49 +120,72 @@ __global__ void __launch_bounds__(64 * 2 * SEG) ltv_fir_kernel(FirArgs g) {
     float* xs = lds + (size_t)g.nfr * g.irs;   // [nfr][XS]
 
     // ---- stage filters and windowed input ----------------------------------------------------
-    // (1) zero the input images (pads must read as zero), 16 B per lane
-    for (int i = tid; i < g.nfr * XS / 4; i += blockDim.x) ((f32x4*)xs)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // (2) filter rows: 32 zeros | n taps | zeros; rows of n floats are 8-byte aligned (n is even)
-    for (int f = 0; f < g.nfr; ++f) {
+    // Wavefront f stages frame m_lo + f on its own: zero image, filter row, windowed input, with every global load
+    // of a step in flight before the first one is consumed (a block-wide loop over the frames paid one load
+    // latency per frame, twice: ~40 us of every launch were staging).  LDS accesses of one wave are ordered, so the
+    // only barrier is the one before the products.
+    for (int f = wave; f < g.nfr; f += 2 * SEG) {
         const int m = m_lo + f;
-        const bool live = (m >= 0 && m <= g.Fr);
-        const int mi = m < g.Fr ? m : g.Fr - 1;
-        const float2* src = (const float2*)(g.ir + ((int64_t)b * g.Fr + (live ? mi : 0)) * g.n);
-        float2* dst = (float2*)(irs + (size_t)f * g.irs);
-        for (int i = tid; i < g.irs / 2; i += blockDim.x) {
-            const int k2 = i - IRPAD / 2;
-            float2 v = {0.f, 0.f};
-            if (live && k2 >= 0 && k2 < g.n / 2) v = src[k2];
-            dst[i] = v;
-        }
-    }
-    __syncthreads();
-    // (3) windowed input: one aligned float4 of x per lane and frame, scattered to image rows r..r+3 of one column
-    for (int f = 0; f < g.nfr; ++f) {
-        const int m = m_lo + f;
-        if (m < 0 || m > g.Fr) continue;
+        if (m < 0 || m > g.Fr) continue;               // the product loop skips these frames too
         float* xd = xs + (size_t)f * XS;
-        const int64_t tb = (int64_t)HOP * (m - 1);
-        for (int z = 4 * tid; z < 2 * HOP; z += 4 * blockDim.x) {
-            const int64_t t = tb + z;
-            if (t < 0 || t >= T) continue;
-            f32x4 x;
-            if (g.excitation == DDSP_EXC_GENERATE) {
+        // (1) zero the input image (pads must read as zero), 16 B per lane
+        for (int i = lane; i < XS / 4; i += 64) ((f32x4*)xd)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // (2) filter row: 32 zeros | n taps | zeros; rows of n floats are 8-byte aligned (n is even)
+        {
+            const int mi = m < g.Fr ? m : g.Fr - 1;
+            const float2* src = (const float2*)(g.ir + ((int64_t)b * g.Fr + mi) * g.n);
+            float2* dst = (float2*)(irs + (size_t)f * g.irs);
+            const int per_row = g.irs / 2, half_n = g.n / 2;
+            for (int base = 0; base < per_row; base += 64 * 8) {
+                float2 v[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = noise_u(g.seed, (uint64_t)b * T + t + e);
-            } else {
-                x = *(const f32x4*)(g.audio + (int64_t)b * T + t);
-                if (g.excitation == DDSP_EXC_UNIT_NOISE) {
+                for (int k = 0; k < 8; ++k) {
+                    const int k2 = base + 64 * k + lane - IRPAD / 2;
+                    v[k] = float2{0.f, 0.f};
+                    if (k2 >= 0 && k2 < half_n) v[k] = src[k2];
+                }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) x[e] = __fadd_rn(__fmul_rn(x[e], 2.0f), -1.0f);
+                for (int k = 0; k < 8; ++k) {
+                    const int i = base + 64 * k + lane;
+                    if (i < per_row) dst[i] = v[k];
                 }
             }
-            const int r0 = z & 15, col = z >> 4;
+        }
+        // (3) windowed input: aligned float4s of x, four per lane, scattered to image rows r..r+3 of one column
+        {
+            const int64_t tb = (int64_t)HOP * (m - 1);
+            f32x4 x[4];
+            bool ok[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int zz = z + e, r = r0 + e;
-                const float w = (zz < HOP) ? (float)zz * (1.0f / HOP) : (float)(2 * HOP - zz) * (1.0f / HOP);
-                xd[r * RS + PADC + col + 2 * (r >> 1)] = x[e] * w;
+            for (int k = 0; k < 4; ++k) {
+                const int z = 4 * (lane + 64 * k);
+                const int64_t t = tb + z;
+                ok[k] = t >= 0 && t < T;
+                x[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (ok[k]) {
+                    if (g.excitation == DDSP_EXC_GENERATE) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[k][e] = noise_u(g.seed, (uint64_t)b * T + t + e);
+                    } else {
+                        x[k] = *(const f32x4*)(g.audio + (int64_t)b * T + t);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!ok[k]) continue;
+                const int z = 4 * (lane + 64 * k);
+                if (g.excitation == DDSP_EXC_UNIT_NOISE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[k][e] = __fadd_rn(__fmul_rn(x[k][e], 2.0f), -1.0f);
+                }
+                const int r0 = z & 15, col = z >> 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int zz = z + e, r = r0 + e;
+                    const float w = (zz < HOP) ? (float)zz * (1.0f / HOP) : (float)(2 * HOP - zz) * (1.0f / HOP);
+                    xd[r * RS + PADC + col + 2 * (r >> 1)] = x[k][e] * w;
+                }
             }
         }
     }
