@@ -30,8 +30,12 @@ def test_register_staged_layouts(ctx, dev, M, N, K, a_kc, b_kc, tile):
     assert float((C.double().cpu() - want).abs().max()) < 2e-6 * scale * max(1.0, K ** 0.5 / 4)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 64, 32), (130, 70, 64), (11008 // 8, 512, 256), (1000, 250, 96), (64, 1536, 1024)])
-@pytest.mark.parametrize("tile", [0, 10, 11, 12])
+# tiles: 0 auto, 10/14 128x64 (3/2 stages), 11/13 128x128 (3/2 stages), 12 256x128, 15/16 64x64 and 64x128 on 4 waves.
+# (4100, 250, 96) and (8200, 1024, 64) make the AUTO choice pick the 4-wave 64x64 tile with ragged M and N, and the
+# 2-stage 128x128 tile with a ragged last row block - the two configurations the Linear layers run at the bench size.
+@pytest.mark.parametrize("M,N,K", [(128, 64, 32), (130, 70, 64), (11008 // 8, 512, 256), (1000, 250, 96), (64, 1536, 1024),
+                                   (4100, 250, 96), (8200, 1024, 64)])
+@pytest.mark.parametrize("tile", [0, 10, 11, 12, 13, 14, 15, 16])
 def test_lds_dma_pipeline(ctx, dev, M, N, K, tile):
     A, B, bias = _mk((M, K), 4, dev), _mk((N, K), 5, dev), _mk((N,), 6, dev)
     C = ctx.gemm(A, B, bias, tile=tile)
