@@ -35,6 +35,55 @@ __global__ void __launch_bounds__(256) k32(float* out, int iters, float a, float
     for (int c = 0; c < CH; ++c) s += acc[c][0] + acc[c][15];
     if (s == 12345.f) out[threadIdx.x] = s;
 }
+// Do fp32 MFMA and vector-ALU instructions of DIFFERENT waves on one SIMD overlap?  Blocks 0..511 run an MFMA loop,
+// blocks 512..1023 a dependent v_fma loop (4 chains per lane); with 4 blocks per CU every SIMD hosts waves of both
+// kinds.  If the two pipes overlap, the mixed launch takes max(T_mfma, T_valu); if they share the issue slot /
+// datapath, it takes about the sum.
+__global__ void __launch_bounds__(256) kmix(float* out, int it_mfma, int it_valu, int mode, float a, float b) {
+    const bool mfma_role = blockIdx.x < gridDim.x / 2;
+    float s = 0.f;
+    if (mfma_role) {
+        if (mode & 1) {
+            f32x4 acc[4];
+            for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < it_mfma; ++i) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[c], 0, 0, 0);
+            }
+            for (int c = 0; c < 4; ++c) s += acc[c][0];
+        }
+    } else if (mode & 2) {
+        float v0 = a, v1 = b, v2 = a + b, v3 = a - b;
+        for (int i = 0; i < it_valu; ++i) {
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                v0 = fmaf(v0, a, b);
+                v1 = fmaf(v1, a, b);
+                v2 = fmaf(v2, a, b);
+                v3 = fmaf(v3, a, b);
+            }
+        }
+        s = (v0 + v1) + (v2 + v3);
+    }
+    if (s == 12345.f) out[threadIdx.x] = s;
+}
+static float time_mix(float* out, int mode) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(kmix, dim3(1024), dim3(256), 0, 0, out, 10, 10, mode, 1.0f, 0.5f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kmix, dim3(1024), dim3(256), 0, 0, out, 4000, 13000, mode, 1.0f, 0.5f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms;
+}
+
 template <class F>
 static void run(const char* name, F launch, double flop_per_mfma, int ch) {
     hipEvent_t e0, e1;
@@ -59,5 +108,8 @@ int main() {
 #define R32(C) run("32x32x2", [&](int b, int it) { hipLaunchKernelGGL(k32<C>, dim3(b), dim3(256), 0, 0, out, it, 1.0f, 0.5f); }, 4096.0, C)
     R32(1); R32(2); R32(4);
     R16(1); R16(2); R16(4); R16(8);
+    const float tm = time_mix(out, 1), tv = time_mix(out, 2), tb = time_mix(out, 3);
+    printf("mixed waves per SIMD: MFMA-only %.3f ms, VALU-only %.3f ms, both %.3f ms  (sum %.3f, max %.3f)\n", tm, tv, tb,
+           tm + tv, tm > tv ? tm : tv);
     return 0;
 }
