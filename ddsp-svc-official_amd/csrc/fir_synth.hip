@@ -183,7 +183,10 @@ extern "C" int ddsp_fir_from_ctrl(ddsp_ctx* ctx, void* stream, int mode, const f
     if (rc) return rc;
     float* tab = nullptr;
     const int kind = mode == DDSP_FIR_ALLPASS ? TAB_IRDFT_CPLX : (mode == DDSP_FIR_STATIC ? TAB_IRDFT_RE_HANN : TAB_IRDFT_RE);
-    rc = ddsp_get_table(ctx, st, kind, M, 0, &tab);
+    // K a multiple of 32 (every shipped n_mag): the table is read tap-major, [n][K], so that both GEMM operands are
+    // k-contiguous and the product runs on the LDS-DMA kernel; otherwise frequency-major on the register-staged one
+    const bool tap_major = K % 32 == 0;
+    rc = ddsp_get_table(ctx, st, kind, M, tap_major ? 1 : 0, &tab);
     if (rc) return rc;
 
     ddsp_prof_begin(ctx, st, PF_FIR_ACT);
@@ -193,20 +196,23 @@ extern "C" int ddsp_fir_from_ctrl(ddsp_ctx* ctx, void* stream, int mode, const f
     DDSP_LAUNCH_CHECK(ctx);
     ddsp_prof_begin(ctx, st, PF_FIR_DFT_GEMM);
 
+    auto run = [&](const gemm::Args& g, const auto& epi) {
+        if (tap_major)
+            gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, epi);
+        else
+            gemm::launch<true, false, gemm::A_PLAIN>(st, g, 1, epi);
+    };
+    const int64_t ldb = tap_major ? K : ddsp_pad4(n);
     if (mode == DDSP_FIR_ALLPASS) {
-        gemm::Args g = gemm::make(act, lda, tab, ddsp_pad4(n), (int)rows, n, K);
-        gemm::EpiStore epi{ir, n, nullptr, 1, 0, 0};
-        gemm::launch<true, false, gemm::A_PLAIN>(st, g, 1, epi);
+        gemm::Args g = gemm::make(act, lda, tab, ldb, (int)rows, n, K);
+        run(g, gemm::EpiStore{ir, n, nullptr, 1, 0, 0});
     } else {
         // even filter: taps 0..n/2 from the GEMM, the rest mirrored by the epilogue
-        gemm::Args g = gemm::make(act, lda, tab, ddsp_pad4(n), (int)rows, n / 2 + 1, K);
-        if (mode == DDSP_FIR_DYNAMIC) {
-            EpiDynWindow epi{ir, n, f0_frames, 1.5f * (float)sr};
-            gemm::launch<true, false, gemm::A_PLAIN>(st, g, 1, epi);
-        } else {
-            EpiMirrorStore epi{ir, n};
-            gemm::launch<true, false, gemm::A_PLAIN>(st, g, 1, epi);
-        }
+        gemm::Args g = gemm::make(act, lda, tab, ldb, (int)rows, n / 2 + 1, K);
+        if (mode == DDSP_FIR_DYNAMIC)
+            run(g, EpiDynWindow{ir, n, f0_frames, 1.5f * (float)sr});
+        else
+            run(g, EpiMirrorStore{ir, n});
     }
     ddsp_prof_end(ctx, st, 2.0 * rows * (double)n * K, 4.0 * rows * (K + n));
     DDSP_LAUNCH_CHECK(ctx);

@@ -12,11 +12,14 @@ constexpr double kTwoPi = 6.283185307179586476925286766559;
 // kind TAB_IRDFT_RE      : rows [0, M)            (real responses, no window)
 // kind TAB_IRDFT_RE_HANN : rows [0, M) times hann_periodic(n)[k]   (ddsp/core.py:262,272,276,287 folded)
 // kind TAB_IRDFT_CPLX    : rows [0, 2M)
-__global__ void irdft_table_kernel(float* __restrict__ tab, int M, int n, int ld, int rows, int hann) {
-    const int64_t total = (int64_t)rows * ld;
+// n1 = 1 (key of the cache): the same table TAP-MAJOR, [n][rows], for the LDS-DMA GEMM of the forward filter synthesis
+// (both operands k-contiguous); the frequency-major layout stays for the backward pass.
+__global__ void irdft_table_kernel(float* __restrict__ tab, int M, int n, int ld, int rows, int hann, int tap_major) {
+    const int64_t total = tap_major ? (int64_t)n * rows : (int64_t)rows * ld;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
-        const int row = (int)(idx / ld), k = (int)(idx % ld);
+        const int row = tap_major ? (int)(idx % rows) : (int)(idx / ld);
+        const int k = tap_major ? (int)(idx / rows) : (int)(idx % ld);
         if (k >= n) {
             tab[idx] = 0.f;
             continue;
@@ -88,10 +91,10 @@ int ddsp_get_table(ddsp_ctx* ctx, hipStream_t st, int kind, int n0, int n1, floa
     switch (kind) {
         case TAB_IRDFT_RE:
         case TAB_IRDFT_RE_HANN:
-            elems = (size_t)n0 * ddsp_pad4(2 * (n0 - 1));
+            elems = n1 ? (size_t)n0 * 2 * (n0 - 1) : (size_t)n0 * ddsp_pad4(2 * (n0 - 1));
             break;
         case TAB_IRDFT_CPLX:
-            elems = (size_t)2 * n0 * ddsp_pad4(2 * (n0 - 1));
+            elems = n1 ? (size_t)2 * n0 * 2 * (n0 - 1) : (size_t)2 * n0 * ddsp_pad4(2 * (n0 - 1));
             break;
         case TAB_RDFT_FWD_W:
             elems = (size_t)n0 * ddsp_pad4(2 * (n0 / 2 + 1));
@@ -110,7 +113,7 @@ int ddsp_get_table(ddsp_ctx* ctx, hipStream_t st, int kind, int n0, int n1, floa
         const int M = n0, n = 2 * (n0 - 1);
         const int rows = kind == TAB_IRDFT_CPLX ? 2 * M : M;
         hipLaunchKernelGGL(irdft_table_kernel, dim3(blocks), dim3(256), 0, st, dev, M, n, ddsp_pad4(n), rows,
-                           kind == TAB_IRDFT_RE_HANN ? 1 : 0);
+                           kind == TAB_IRDFT_RE_HANN ? 1 : 0, n1 ? 1 : 0);
     } else {
         hipLaunchKernelGGL(rdft_w_table_kernel, dim3(blocks), dim3(256), 0, st, dev, n0,
                            ddsp_pad4(2 * (n0 / 2 + 1)), kind == TAB_RDFT_INV_W ? 1 : 0);
