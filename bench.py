@@ -46,7 +46,10 @@ def measured_traffic():
     d = json.load(open(files[-1]))
     tot = n = 0.0
     for k, v in d.items():
-        if "kernel_dma" in k and ", 1>(" not in k:     # Linear layers only (A_MODE 1 = the prenet convs' instantiation)
+        # the Linear layers' instantiations at the bench shape (QKV, pw1+GLU, out-projection / pw2, head); the same
+        # kernel template also runs the prenet convs and the filter-synthesis DFTs, which are other families
+        if "kernel_dma" in k and any(t in k for t in ("EpiSplit3", "EpiGlu", "EpiResidual",
+                                                      "kernel_dma<128, 128, gemm::EpiStore")):
             tot += v["hbm_bytes_per_launch"] * v["launches_sampled"]
             n += v["launches_sampled"]
     return tot / n if n else None
