@@ -21,6 +21,38 @@ from hipddsp import (COMB_SINC, COMB_SINC_GATED, COMB_NONE, EXC_AUDIO, EXC_GENER
 from .unit2control import Unit2Control
 
 
+class Volume_Extractor:
+    """Frame RMS of an audio signal on the device (reference `ddsp/vocoder.py:116-137`, same constructor and method).
+
+    `extract(audio)`: a numpy array (T,) as the reference's callers pass (`main.py`, `preprocess.py`) comes back as a
+    numpy array (Frame,) - it is copied to `device`, reduced there and copied back; a device tensor (T,) or (B,T)
+    comes back as a device tensor of the same rank.  There is no CPU computation path."""
+
+    def __init__(self, hop_size=512, device="cuda"):
+        self.hop_size = hop_size
+        self.device = device
+
+    def extract(self, audio):
+        import numpy as np
+        is_np = isinstance(audio, np.ndarray)
+        x = torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float32)).to(self.device) if is_np else audio
+        if not x.is_cuda:
+            raise RuntimeError("Volume_Extractor runs on a HIP device only (no CPU fallback)")
+        flat = x.dim() == 1
+        vol = hipddsp.context_for(x.device).volume_extract(x.reshape(1, -1) if flat else x, int(self.hop_size))
+        vol = vol[0] if flat else vol
+        return vol.cpu().numpy() if is_np else vol
+
+
+def align_units(units, n_samples, sample_rate, hop_size, encoder_sample_rate=16000, encoder_hop_size=320):
+    """Nearest-frame alignment of encoder units (B, Lu, C) to the synthesiser's frames - the tail of the reference's
+    `Units_Encoder.encode` (`ddsp/vocoder.py:201-211`), for callers that keep the reference's encoders and want the
+    gather on the device: n_frames = n_samples // hop_size + 1, row i takes unit min(round(ratio * i), Lu - 1)."""
+    n_frames = int(n_samples) // int(hop_size) + 1
+    ratio = (hop_size / sample_rate) / (encoder_hop_size / encoder_sample_rate)
+    return hipddsp.context_for(units.device).align_units(units, n_frames, ratio)
+
+
 class DotDict(dict):
     """Attribute access to nested config dicts (reference `ddsp/vocoder.py:335-341`)."""
 

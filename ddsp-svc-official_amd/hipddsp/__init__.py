@@ -66,6 +66,8 @@ SIGNATURES = {
     "ddsp_rss_loss": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _c.POINTER(_int), _int, _f32, _f32, _vp, _vp]),
     "ddsp_sola": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp]),
     "ddsp_volume_gate": (_int, [_vp, _vp, _vp, _vp, _f32, _i64, _i64, _int]),
+    "ddsp_volume_extract": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp]),
+    "ddsp_align_units": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp]),
     "ddsp_adamw_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64]),
     "ddsp_adamw_step_multi": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _i64]),
     "ddsp_gemm_f32": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _i64, _int, _vp, _vp, _i64, _int, _int, _int, _int, _int]),
@@ -290,6 +292,27 @@ class Context:
         f0 = None if f0_frames is None else f0_frames.reshape(-1).contiguous().float()
         self.call("ddsp_fir_from_ctrl_bwd", int(mode), _ptr(ctrl2d) + 4 * col0, ctrl2d.shape[-1], int(n_mag), _ptr(f0),
                   rows, int(sr), _ptr(d_ir), _ptr(d_ctrl2d) + 4 * col0, d_ctrl2d.shape[-1])
+
+    # -- front-end steps -----------------------------------------------------
+    def volume_extract(self, audio, hop):
+        """audio (B,T) fp32 -> (B, T//hop + 1) block RMS with numpy-'reflect' padding (ddsp/vocoder.py:116-137)."""
+        audio = audio.contiguous().float()
+        B, T = audio.shape
+        out = torch.empty(B, T // int(hop) + 1, device=audio.device, dtype=torch.float32)
+        if B == 0:
+            return out
+        self.call("ddsp_volume_extract", _ptr(audio), B, T, int(hop), _ptr(out))
+        return out
+
+    def align_units(self, units, n_frames, ratio):
+        """units (B,Lu,C) -> (B,n_frames,C), row i = units[:, min(rint(fp32(ratio)*i), Lu-1)] (ddsp/vocoder.py:201-211)."""
+        units = units.contiguous().float()
+        B, Lu, C = units.shape
+        out = torch.empty(B, int(n_frames), C, device=units.device, dtype=torch.float32)
+        if B == 0 or int(n_frames) == 0:
+            return out
+        self.call("ddsp_align_units", _ptr(units), B, Lu, C, int(n_frames), float(ratio), _ptr(out))
+        return out
 
     # -- a15 optimiser -------------------------------------------------------------------------
     def adamw_step(self, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):

@@ -194,6 +194,18 @@ int ddsp_sola(ddsp_ctx* ctx, void* stream, const float* audio, int64_t n_audio, 
 int ddsp_volume_gate(ddsp_ctx* ctx, void* stream, float* signal, const float* volume, float threshold, int64_t B,
                      int64_t Fr, int hop);
 
+/* ---- the device-side steps immediately before the synthesis path ------------- */
+/* replaces ddsp/vocoder.py:116-137 `Volume_Extractor.extract`: audio (B,T) -> volume (B, T/hop + 1), the RMS of
+ * non-overlapping hop-sized blocks of the signal reflect-padded by (hop/2, (hop+1)/2) (numpy 'reflect': T must
+ * exceed (hop+1)/2). */
+int ddsp_volume_extract(ddsp_ctx* ctx, void* stream, const float* audio, int64_t B, int64_t T, int hop,
+                        float* volume);
+/* replaces the alignment tail of ddsp/vocoder.py:201-211 `Units_Encoder.encode`: out[b][i][:] = units[b][j][:] with
+ * j = min(rint(ratio * i), Lu - 1), ratio = (hop/sample_rate) / (encoder_hop/encoder_sample_rate) as fp32, rint =
+ * round half to even (torch.round); units (B,Lu,C) -> out (B,n_frames,C). */
+int ddsp_align_units(ddsp_ctx* ctx, void* stream, const float* units, int64_t B, int64_t Lu, int64_t C,
+                     int64_t n_frames, float ratio, float* out);
+
 /* ---- a15: optimiser step --------------------------------------------------------------------- */
 /* replaces one parameter's update of torch.optim.AdamW (train.py:41, solver.py:114): decoupled weight decay,
  * bias-corrected moments, `step` counted from 1.  All buffers hold n fp32 values. */

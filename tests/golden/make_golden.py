@@ -15,6 +15,8 @@ reference's own code.  Weights come from the product's seeded constructors via l
 excitation is injected by patching torch.rand_like for the duration of the forward.
 Tier C (`glue_*.npz`): caller-side expressions of main.py / gui.py (SOLA splice, slice cross-fade, volume
 gate) evaluated verbatim on synthetic data.
+Tier D (`glue_frontend.npz`): the reference's `Volume_Extractor.extract` and the alignment tail of
+`Units_Encoder.encode`, see `tier_d`.
 """
 import os
 import sys
@@ -293,8 +295,44 @@ def tier_c():
     save("glue_offline.npz", a=a, b=b, idx=idx, crossfaded=res, volume=vol, mask_frames=mask, mask_up=mask_up[:, ::16])
 
 
+# ------------------------------------------------------------------------------------------------
+FRONTEND_VOLUME = [(88064, 512), (44100, 512), (1000, 64), (513, 512), (700, 441), (5000, 7)]      # (T, hop)
+# (n_samples, sample_rate, hop_size, Lu, C): the usual 44.1 kHz / 512 against 16 kHz / 320 units (ratio 0.58), equal
+# rates (ratio 1), ratio 1.5 (ties: half to even), too few units (the clamp), a hop from main.py's resampled case
+FRONTEND_ALIGN = [(88064, 44100, 512, 101, 256), (32000, 16000, 320, 101, 64), (16000, 16000, 480, 40, 8),
+                  (88064, 44100, 512, 60, 12), (48000, 48000, 557, 52, 768)]
+
+
+def tier_d():
+    """`Volume_Extractor.extract` and the alignment tail of `Units_Encoder.encode`, run from the
+    reference's `ddsp/vocoder.py` (imported with the tier-B placeholders).  `Units_Encoder` is instantiated without its
+    constructor (that would load a HuBERT checkpoint): `model` is a stand-in returning the prepared units and the
+    resampler slot holds an identity, so `encode` executes the reference's own index arithmetic and gather."""
+    import warnings
+    warnings.simplefilter("ignore")
+    _placeholders()
+    for k in [k for k in sys.modules if k == "ddsp" or k.startswith("ddsp.")]:
+        del sys.modules[k]
+    sys.path.insert(0, REF)
+    import ddsp.vocoder as RV
+    sys.path.remove(REF)
+    out = {}
+    for i, (T, hop) in enumerate(FRONTEND_VOLUME):
+        audio = rng(700 + i).uniform(-1, 1, size=T).astype(np.float32)
+        out[f"vol_{i}"] = RV.Volume_Extractor(hop).extract(audio)
+    for i, (n, sr, hop, Lu, C) in enumerate(FRONTEND_ALIGN):
+        units = t32(rng(800 + i).standard_normal((1, Lu, C)))
+        enc = object.__new__(RV.Units_Encoder)
+        enc.device = "cpu"
+        enc.model = lambda a, u=units: u
+        enc.resample_kernel = {str(sr): (lambda a: a)}
+        enc.encoder_sample_rate, enc.encoder_hop_size = 16000, 320
+        out[f"align_{i}"] = enc.encode(torch.zeros(1, n), sr, hop)
+    save("glue_frontend.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["a", "b", "c"]
+    which = sys.argv[1:] or ["a", "b", "c", "d"]
     torch.set_num_threads(4)
     if "a" in which:
         tier_a()
@@ -302,3 +340,5 @@ if __name__ == "__main__":
         tier_c()
     if "b" in which:
         tier_b()
+    if "d" in which:
+        tier_d()

@@ -172,3 +172,25 @@ def test_offline_glue_golden():
     assert np.array_equal(out, z["crossfaded"])
     gate = RT.volume_gate(z["volume"], -60, HOP)
     assert (gate[:, ::16] - torch.from_numpy(z["mask_up"])).abs().max() < 1e-6
+
+
+# ---- tier D: front-end steps before the path against the reference's own outputs --------------
+def test_frontend_golden():
+    from frontend_cases import FRONTEND_VOLUME, FRONTEND_ALIGN, volume_audio, align_units_input
+    from oracle import frontend as F
+    g = load("glue_frontend.npz")
+    for i in range(len(FRONTEND_VOLUME)):
+        audio, hop = volume_audio(i)
+        got = F.volume_extract(audio, hop)
+        want = g[f"vol_{i}"].numpy()
+        assert got.shape == want.shape == (len(audio) // hop + 1,)
+        assert np.allclose(got, want, rtol=1e-6, atol=0), i
+    for i in range(len(FRONTEND_ALIGN)):
+        units, n, sr, hop = align_units_input(i)
+        got = F.align_units(units, n, sr, hop)
+        assert torch.equal(got, g[f"align_{i}"]), i
+    # the fixture contains the cases it is meant to: a clamped tail and a tie rounded to even
+    u, n, sr, hop = align_units_input(3)
+    assert torch.equal(g["align_3"][0, -1], u[0, -1]) and torch.equal(g["align_3"][0, -5], u[0, -1])
+    u, n, sr, hop = align_units_input(2)                      # ratio 1.5: frame 1 -> unit 2 (1.5), frame 3 -> unit 4 (4.5)
+    assert torch.equal(g["align_2"][0, 1], u[0, 2]) and torch.equal(g["align_2"][0, 3], u[0, 4])

@@ -47,6 +47,14 @@ ps = ctx.phase_scan(f0, 512, 44100, None, True, 0, want_phase=True)
 t = timeit(lambda: ctx.sins_bank(ctrl, 0, H, f0, ps["phase"], B, Fr, 512, 44100))
 out["sins256_bank_only_B64"] = {"ms": t * 1e3, "samples_per_s": B * Fr * 512 / t, "hbm_GBps_algorithmic": 6.01 * B * Fr * 512 / t / 1e9}
 
+# the front-end steps before the path, at the bench batch (HBM-bound: algorithmic GB/s)
+audio = torch.rand(B, Fr * 512, device=dev) * 2 - 1
+t = timeit(lambda: ctx.volume_extract(audio, 512), n=50)
+out["volume_extract_B64"] = {"ms": t * 1e3, "GBps_algorithmic": 4.0 * B * (Fr * 512 + Fr + 1) / t / 1e9}
+units_raw = torch.randn(B, 101, 256, device=dev)
+t = timeit(lambda: ctx.align_units(units_raw, Fr + 1, (512 / 44100) / (320 / 16000)), n=50)
+out["align_units_B64"] = {"ms": t * 1e3, "GBps_algorithmic": 8.0 * B * (Fr + 1) * 256 / t / 1e9}
+
 # real-time block: window of 44 100 samples at 44.1 kHz -> Fr = 87, B = 1, then SOLA splice
 model, cfg = synthetic.build_model("CombSub", seed=1, device=dev)
 inp = {k: v.to(dev) for k, v in synthetic.make_inputs(5, 1, 87, with_noise=False).items()}
