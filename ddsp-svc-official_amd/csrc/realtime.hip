@@ -106,7 +106,94 @@ __global__ void __launch_bounds__(256) volume_gate_kernel(float* __restrict__ si
     }
 }
 
+// ---- phase-vocoder cross-fade (gui.py:14-31, optional `use_phase_vocoder` splice of gui.py:417-423) ----------------
+// result[t] = a[t]*fo[t]^2 + b[t]*fi[t]^2 + (sum_f A_f cos(w_f * t/n + phi_f)) * fo[t] * fi[t] / n  with, per rfft bin f,
+//   A_f = (|Fa_f| + |Fb_f|) * (2 inside the spectrum, 1 at DC and at the Nyquist bin of an even n),
+//   phi_f = angle(Fa_f),  w_f = 2 pi f + wrap(angle(Fb_f) - angle(Fa_f)),  wrap(x) = x - 2 pi floor(x/2/pi + 0.5).
+// The per-bin frequencies are not harmonic, so the synthesis is a dense n x (n/2+1) cosine sum, not an inverse FFT.
+// All fp32 steps after the two DFTs follow the reference's operation order (the argument w*t + phi reaches 5.5e3 rad at
+// n = 1764: its fp32 rounding, 2.4e-4 rad, is part of the reference's result).
+// (1) one wavefront per bin: direct DFT of a and b with exact integer phase reduction
+__global__ void __launch_bounds__(256) pv_spectrum_kernel(const float* __restrict__ a, const float* __restrict__ b, int n,
+                                                          float* __restrict__ amp, float* __restrict__ phia,
+                                                          float* __restrict__ wf) {
+    const int lane = threadIdx.x & 63;
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int F = n / 2 + 1;
+    if (f >= F) return;
+    double ra = 0, ia = 0, rb = 0, ib = 0;
+    for (int t = lane; t < n; t += 64) {
+        const int r = (int)(((int64_t)f * t) % n);
+        double sn, cs;
+        sincos(-6.283185307179586476925286766559 * (double)r / (double)n, &sn, &cs);
+        const double xa = a[t], xb = b[t];
+        ra += xa * cs;
+        ia += xa * sn;
+        rb += xb * cs;
+        ib += xb * sn;
+    }
+    ra = wave_sum_d(ra);
+    ia = wave_sum_d(ia);
+    rb = wave_sum_d(rb);
+    ib = wave_sum_d(ib);
+    if (lane == 0) {
+        const float fra = (float)ra, fia = (float)ia, frb = (float)rb, fib = (float)ib;   // complex64 spectra
+        float ab = hypotf(fra, fia) + hypotf(frb, fib);
+        const bool inner = (n % 2 == 0) ? (f >= 1 && f <= F - 2) : (f >= 1);
+        if (inner) ab = __fmul_rn(ab, 2.0f);
+        const float pa = atan2f(fia, fra), pb = atan2f(fib, frb);
+        float d = __fsub_rn(pb, pa);
+        // deltaphase - 2*pi*floor(deltaphase / 2 / pi + 0.5), every step rounded to fp32 like the tensor expression
+        const float k = floorf(__fadd_rn(__fdiv_rn(__fdiv_rn(d, 2.0f), 3.14159274101257324f), 0.5f));
+        d = __fsub_rn(d, __fmul_rn(6.28318548202514648f, k));
+        amp[f] = ab;
+        phia[f] = pa;
+        wf[f] = __fadd_rn(__fmul_rn(6.28318548202514648f, (float)f), d);
+    }
+}
+
+// (2) one wavefront per output sample: the cosine sum over the bins, then the three-term mix
+__global__ void __launch_bounds__(256) pv_synth_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       const float* __restrict__ fo, const float* __restrict__ fi, int n,
+                                                       const float* __restrict__ amp, const float* __restrict__ phia,
+                                                       const float* __restrict__ wf, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n) return;
+    const int F = n / 2 + 1;
+    const float tt = __fdiv_rn((float)t, (float)n);
+    float s = 0.f;
+    for (int f = lane; f < F; f += 64) s += __fmul_rn(amp[f], cosf(__fadd_rn(__fmul_rn(wf[f], tt), phia[f])));
+    s = wave_sum(s);
+    if (lane == 0) {
+        const float o = fo[t], i = fi[t];
+        const float osc = __fdiv_rn(__fmul_rn(__fmul_rn(s, o), i), (float)n);
+        out[t] = __fadd_rn(__fadd_rn(__fmul_rn(a[t], __fmul_rn(o, o)), __fmul_rn(b[t], __fmul_rn(i, i))), osc);
+    }
+}
+
 }  // namespace
+
+extern "C" int ddsp_phase_vocoder(ddsp_ctx* ctx, void* stream, const float* a, const float* b, const float* fade_out,
+                                  const float* fade_in, int n, float* out) {
+    DDSP_REQUIRE(ctx, ctx && a && b && fade_out && fade_in && out, "ddsp_phase_vocoder: null argument");
+    DDSP_REQUIRE(ctx, n >= 2 && n <= (1 << 16), "ddsp_phase_vocoder: bad length");
+    hipStream_t st = (hipStream_t)stream;
+    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    const int F = n / 2 + 1;
+    int rc = ddsp_scratch_reserve_bytes(ctx, (size_t)3 * F * sizeof(float) + 4096);
+    if (rc) return rc;
+    ddsp_scratch_reset(ctx);
+    float* spec = nullptr;
+    if ((rc = ddsp_scratch_get(ctx, (size_t)3 * F * sizeof(float), (void**)&spec))) return rc;
+    ddsp_prof_begin(ctx, st, PF_SOLA);
+    hipLaunchKernelGGL(pv_spectrum_kernel, dim3((F + 3) / 4), dim3(256), 0, st, a, b, n, spec, spec + F, spec + 2 * F);
+    hipLaunchKernelGGL(pv_synth_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a, b, fade_out, fade_in, n, spec, spec + F,
+                       spec + 2 * F, out);
+    ddsp_prof_end(ctx, st, 10.0 * n * (double)F, 4.0 * 5 * n);
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}
 
 extern "C" int ddsp_sola(ddsp_ctx* ctx, void* stream, const float* audio, int64_t n_audio, int block, int xfade,
                          int search, int delay, float* sola_buffer, float* emitted, int* shift) {

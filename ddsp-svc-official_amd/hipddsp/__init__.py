@@ -66,6 +66,7 @@ SIGNATURES = {
     "ddsp_rss_loss": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _c.POINTER(_int), _int, _f32, _f32, _vp, _vp]),
     "ddsp_sola": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp]),
     "ddsp_volume_gate": (_int, [_vp, _vp, _vp, _vp, _f32, _i64, _i64, _int]),
+    "ddsp_phase_vocoder": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
     "ddsp_volume_extract": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp]),
     "ddsp_align_units": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp]),
     "ddsp_adamw_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64]),
@@ -402,6 +403,18 @@ class Context:
         self.call("ddsp_sola", _ptr(audio), audio.numel(), int(block), int(xfade), int(search), int(delay),
                   _ptr(sola_buffer), _ptr(emitted), _ptr(shift))
         return emitted, shift
+
+    def phase_vocoder(self, a, b, fade_out, fade_in):
+        """gui.py:14-31: cross-fade of the kept tail `a` into the new head `b` (both (n,)) with a phase-interpolated
+        oscillator term; returns (n,)."""
+        a, b = a.contiguous().float(), b.contiguous().float()
+        fo, fi = fade_out.contiguous().float(), fade_in.contiguous().float()
+        n = a.numel()
+        if not (b.numel() == fo.numel() == fi.numel() == n):
+            raise ValueError("phase_vocoder: a, b and the fade windows must have the same length")
+        out = torch.empty(n, device=a.device, dtype=torch.float32)
+        self.call("ddsp_phase_vocoder", _ptr(a), _ptr(b), _ptr(fo), _ptr(fi), n, _ptr(out))
+        return out
 
     # -- a15 -----------------------------------------------------------------------------------
     def volume_gate_(self, signal, volume, threshold_db, hop):

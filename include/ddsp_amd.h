@@ -189,6 +189,11 @@ int ddsp_sola(ddsp_ctx* ctx, void* stream, const float* audio, int64_t n_audio, 
               int delay, float* sola_buffer, float* emitted, int* shift);
 
 /* ---- a15: volume gate ------------------------------------------------------------------------ */
+/* replaces gui.py:14-31 `phase_vocoder(a, b, fade_out, fade_in)` (the optional cross-fade of gui.py:417-423; SURVEY
+ * 8(f) rank 3): a = kept tail, b = head of the new block, both (n), fade windows (n), out (n).  n <= 65536. */
+int ddsp_phase_vocoder(ddsp_ctx* ctx, void* stream, const float* a, const float* b, const float* fade_out,
+                       const float* fade_in, int n, float* out);
+
 /* replaces main.py:111-116,159 / gui.py:108-112,127: signal (B,T) *= upsample(dilate9(volume > threshold)),
  * in place (threshold = 10^(dB/20), linear); volume (B,Fr). */
 int ddsp_volume_gate(ddsp_ctx* ctx, void* stream, float* signal, const float* volume, float threshold, int64_t B,

@@ -58,3 +58,25 @@ def volume_gate(volume, threshold_db, hop):
     m = np.array([np.max(m[n: n + 9]) for n in range(len(m) - 8)])
     m = torch.from_numpy(m).float()[None, :, None]
     return dsp.frames_to_samples(m, hop).squeeze(-1)
+
+
+def phase_vocoder(a, b, fade_out, fade_in):
+    """ref: gui.py:14-31 (the optional cross-fade of gui.py:417-423).  Spectra of the kept tail `a` and the new head
+    `b`; per bin the summed magnitudes (doubled inside the spectrum), the phase of `a`, and the phase advance to `b`
+    wrapped into [-pi, pi) and added to the bin's own 2*pi*f; an oscillator bank with those per-bin frequencies is
+    mixed in with weight fade_out*fade_in/n next to the squared-window cross-fade of the two signals."""
+    import numpy as np
+    n = a.shape[0]
+    Fa, Fb = torch.fft.rfft(a), torch.fft.rfft(b)
+    amp = Fa.abs() + Fb.abs()
+    if n % 2 == 0:
+        amp[1:-1] *= 2
+    else:
+        amp[1:] *= 2
+    pa, pb = torch.angle(Fa), torch.angle(Fb)
+    d = pb - pa
+    d = d - 2 * np.pi * torch.floor(d / 2 / np.pi + 0.5)
+    w = 2 * np.pi * torch.arange(n // 2 + 1).to(a) + d
+    t = torch.arange(n).unsqueeze(-1).to(a) / n
+    osc = torch.sum(amp * torch.cos(w * t + pa), -1)
+    return a * (fade_out ** 2) + b * (fade_in ** 2) + osc * fade_out * fade_in / n

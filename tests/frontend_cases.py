@@ -19,3 +19,19 @@ def volume_audio(i):
 def align_units_input(i):
     n, sr, hop, Lu, C = FRONTEND_ALIGN[i]
     return torch.from_numpy(_rng(800 + i).standard_normal((1, Lu, C)).astype(np.float32)), n, sr, hop
+
+
+# ---- phase-vocoder cross-fade (tests/golden/glue_phase_vocoder.npz; the same inputs as make_golden.py pv_inputs) ----
+PV_SIZES = [1764, 441, 64]
+SR = 44100
+
+
+def pv_inputs(i):
+    n = PV_SIZES[i]
+    r = _rng(900 + i)
+    t = np.arange(n) / SR
+    a = 0.3 * np.sin(2 * np.pi * 220.0 * t + 0.4) + 0.1 * np.sin(2 * np.pi * 1330.0 * t + 1.1) + 0.01 * r.standard_normal(n)
+    b = 0.3 * np.sin(2 * np.pi * 220.0 * t + 1.3) + 0.1 * np.sin(2 * np.pi * 1330.0 * t - 0.6) + 0.01 * r.standard_normal(n)
+    fi = torch.sin(np.pi * torch.arange(0, 1, 1 / n) / 2)[:n] ** 2
+    f32 = lambda x: torch.from_numpy(np.asarray(x, dtype=np.float32))
+    return f32(a), f32(b), 1 - fi, fi

@@ -303,6 +303,21 @@ FRONTEND_ALIGN = [(88064, 44100, 512, 101, 256), (32000, 16000, 320, 101, 64), (
                   (88064, 44100, 512, 60, 12), (48000, 48000, 557, 52, 768)]
 
 
+PV_SIZES = [1764, 441, 64]      # gui.py's 0.04 s cross-fade at 44.1 kHz, an odd length, a small even one
+
+
+def pv_inputs(i):
+    """Kept tail `a` and new head `b`: the same two partials with shifted phases plus a little noise, and the sin^2 /
+    cos^2 windows of gui.py:349-351."""
+    n = PV_SIZES[i]
+    r = rng(900 + i)
+    t = np.arange(n) / SR
+    a = 0.3 * np.sin(2 * np.pi * 220.0 * t + 0.4) + 0.1 * np.sin(2 * np.pi * 1330.0 * t + 1.1) + 0.01 * r.standard_normal(n)
+    b = 0.3 * np.sin(2 * np.pi * 220.0 * t + 1.3) + 0.1 * np.sin(2 * np.pi * 1330.0 * t - 0.6) + 0.01 * r.standard_normal(n)
+    fi = torch.sin(np.pi * torch.arange(0, 1, 1 / n) / 2)[:n] ** 2
+    return t32(a), t32(b), 1 - fi, fi
+
+
 def tier_d():
     """`Volume_Extractor.extract` and the alignment tail of `Units_Encoder.encode`, run from the
     reference's `ddsp/vocoder.py` (imported with the tier-B placeholders).  `Units_Encoder` is instantiated without its
@@ -329,6 +344,25 @@ def tier_d():
         enc.encoder_sample_rate, enc.encoder_hop_size = 16000, 320
         out[f"align_{i}"] = enc.encode(torch.zeros(1, n), sr, hop)
     save("glue_frontend.npz", **out)
+
+    # phase-vocoder cross-fade of gui.py:14-31: gui.py imported with placeholders for its GUI /
+    # audio-device / analysis imports, the function itself is the reference's
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+    for name in ("PySimpleGUI", "sounddevice", "librosa"):
+        mod(name)
+    mod("enhancer", Enhancer=object)
+    sys.path.insert(0, REF)
+    import gui as RG
+    sys.path.remove(REF)
+    pv = {}
+    for i, n in enumerate(PV_SIZES):
+        a, b, fo, fi = pv_inputs(i)
+        pv[f"pv_{i}"] = RG.phase_vocoder(a, b, fo, fi)
+    save("glue_phase_vocoder.npz", **pv)
 
 
 if __name__ == "__main__":

@@ -139,3 +139,46 @@ def test_graphed_forward_equals_eager(dev, lib_path):
         g.ctx.upsample(torch.zeros(1, 2, 1, device=dev), 512)       # frozen: owned by the graph
     with pytest.raises(ValueError):
         g(inp["units"][:, :5], inp["f0"][:, :5], inp["volume"][:, :5], inp["spk_id"])
+
+
+def test_phase_vocoder_matches_reference(dev, lib_path):
+    """`ddsp_phase_vocoder` against the reference's own `gui.phase_vocoder` outputs for the GUI's
+    1764-sample cross-fade, an odd length and a short even one.  The kernels repeat the reference's fp32 operation
+    order after the DFTs (its oscillator arguments reach 5.5e3 rad, so that order is part of the result); measured
+    error 3e-7 max / 7e-8 RMS on a 0.22-RMS signal (tools/pv_check.py), asserted at 5e-6 / 1e-6."""
+    import realtime
+    from frontend_cases import PV_SIZES, pv_inputs
+    g = np.load(os.path.join(GOLDEN, "glue_phase_vocoder.npz"))
+    for i, n in enumerate(PV_SIZES):
+        a, b, fo, fi = pv_inputs(i)
+        got = realtime.phase_vocoder(a.to(dev), b.to(dev), fo.to(dev), fi.to(dev)).cpu()
+        want = torch.from_numpy(g[f"pv_{i}"])
+        assert got.shape == want.shape == (n,)
+        err = (got - want).abs()
+        assert float(err.max()) < 5e-6 and float(err.pow(2).mean().sqrt()) < 1e-6, (n, float(err.max()))
+        # ends: pure `a` at t = 0 (fade_out = 1), and the oscillator term vanishes where a window is 0
+        assert abs(float(got[0]) - float(a[0])) < 1e-6
+    with pytest.raises(ValueError):
+        realtime.phase_vocoder(a.to(dev), b[:10].to(dev), fo.to(dev), fi.to(dev))
+
+
+def test_splicer_with_phase_vocoder(dev, lib_path):
+    """Splicer(use_phase_vocoder=True): same SOLA shift and same samples after the cross-fade region as the linear
+    splice; the head equals phase_vocoder(kept tail, new head at the shift)."""
+    import realtime
+    sr = 44100
+    n = 44544
+    t = torch.arange(n) / sr
+    mk = lambda ph: (0.3 * torch.sin(2 * torch.pi * 220.0 * t + ph)).to(dev)
+    lin = realtime.Splicer(sr, 0.2, 0.04, dev)
+    pv = realtime.Splicer(sr, 0.2, 0.04, dev, use_phase_vocoder=True)
+    for ph in (0.0, 0.7, 1.9):
+        x = mk(ph)
+        kept = pv.buffer.clone()
+        e_lin, e_pv = lin.push(x), pv.push(x)
+        assert int(lin.last_shift) == int(pv.last_shift)
+        assert torch.equal(e_lin[pv.xfade:], e_pv[pv.xfade:])
+        assert torch.equal(lin.buffer, pv.buffer)
+        start = n - pv.block - pv.xfade - pv.search - pv.delay + int(pv.last_shift)
+        want = realtime.phase_vocoder(kept, x[start:start + pv.xfade], pv.fade_out, pv.fade_in)
+        assert torch.equal(e_pv[:pv.xfade], want)

@@ -194,3 +194,15 @@ def test_frontend_golden():
     assert torch.equal(g["align_3"][0, -1], u[0, -1]) and torch.equal(g["align_3"][0, -5], u[0, -1])
     u, n, sr, hop = align_units_input(2)                      # ratio 1.5: frame 1 -> unit 2 (1.5), frame 3 -> unit 4 (4.5)
     assert torch.equal(g["align_2"][0, 1], u[0, 2]) and torch.equal(g["align_2"][0, 3], u[0, 4])
+
+
+def test_phase_vocoder_golden():
+    """oracle/realtime.phase_vocoder against the reference's gui.phase_vocoder (tests/golden/glue_phase_vocoder.npz)."""
+    from frontend_cases import PV_SIZES, pv_inputs
+    from oracle import realtime as RT
+    g = load("glue_phase_vocoder.npz")
+    for i, n in enumerate(PV_SIZES):
+        a, b, fo, fi = pv_inputs(i)
+        got = RT.phase_vocoder(a, b, fo, fi)
+        assert got.shape == (n,)
+        assert close(got, g[f"pv_{i}"]), i
