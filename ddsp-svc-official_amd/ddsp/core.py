@@ -84,6 +84,8 @@ def frequency_filter(audio, magnitudes, hann_window=True, half_width_frames=None
     """
     if audio.requires_grad or magnitudes.requires_grad or (half_width_frames is not None and half_width_frames.requires_grad):
         raise NotImplementedError("ddsp.core.frequency_filter is forward-only on the device path; train through the model classes")
+    if not (audio.is_cuda and magnitudes.is_cuda):
+        raise RuntimeError("ddsp.core.frequency_filter needs device tensors (no CPU fallback)")
     if audio.dim() != 2 or magnitudes.dim() != 3 or audio.shape[0] != magnitudes.shape[0]:
         raise ValueError("frequency_filter: audio (B, T) and magnitudes (B, Frame, n_mag) expected")
     B, T = audio.shape
