@@ -101,20 +101,32 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the synthesis path has no CPU fallback")
+    # Rehearsal switch (never set by the driver): DDSP_BENCH_REHEARSAL=gloo runs the N > 1 control flow - rendezvous,
+    # barriers, the overlapped all_gather, the max-over-ranks timing, rank-0 reporting, teardown - with several ranks
+    # sharing the ONE GPU of a test box (ranks map to cuda:(local % device_count), collectives go through gloo).  The
+    # numbers of such a run mean nothing; it exists so that the multi-rank path is executed before the 8-GPU run.
+    rehearsal = os.environ.get("DDSP_BENCH_REHEARSAL", "")
+    if rehearsal:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group(rehearsal)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import hipddsp
     import synthetic
     import sharding
 
     seed = synthetic.BASE_SEED + 2
-    model, cfg = synthetic.build_model(args.model, seed=seed, device=dev)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):      # the constructors print the reference's banner line; stdout is for the JSON
+        model, cfg = synthetic.build_model(args.model, seed=seed, device=dev)
     inp = synthetic.make_inputs(seed + 100 + rank, B_PER_GPU, FRAMES, with_noise=False)
     inp = {k: v.to(dev) for k, v in inp.items()}
     T = FRAMES * HOP
