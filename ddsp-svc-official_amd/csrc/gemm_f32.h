@@ -42,6 +42,9 @@ struct Args {
     // conv3 mode
     int Fr, Cin;
     const float* zeros;   // >= Cin + 32 zero floats (DMA kernel, conv3 mode: source of the taps that fall off an utterance)
+    // remainder mode of the DMA kernel (sub_from > 0): tile t of this launch is quadrant t & 3 of the PARENT tiling's tile
+    // sub_from + t / 4, the parent tiles being twice as large in both directions and parent_tn of them per row
+    int sub_from, parent_tn;
 };
 
 constexpr int BK = 32;
@@ -361,8 +364,14 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ?
     const float* src_p1[PA];
     auto tile_src = [&](int tile, const float* (&src)[PPW]) {
         const int per_z = tiles_m * tiles_n;
-        const int z = tile / per_z, rem = tile - z * per_z;
-        const int m0 = (rem / tiles_n) * BM, n0 = (rem % tiles_n) * BN;
+        int z = tile / per_z, rem = tile - z * per_z;
+        int m0 = (rem / tiles_n) * BM, n0 = (rem % tiles_n) * BN;
+        if (g.sub_from > 0) {                     // remainder mode: quadrants of the parent tiling's last tiles
+            const int big = g.sub_from + (tile >> 2), q = tile & 3;
+            z = 0;
+            m0 = (2 * (big / g.parent_tn) + (q >> 1)) * BM;
+            n0 = (2 * (big % g.parent_tn) + (q & 1)) * BN;
+        }
         const float* A = g.A + (int64_t)(z / g.zdiv) * g.sA_hi + (int64_t)(z % g.zdiv) * g.sA_lo;
         const float* B = g.B + (int64_t)(z / g.zdiv) * g.sB_hi + (int64_t)(z % g.zdiv) * g.sB_lo;
 #pragma unroll
@@ -478,8 +487,14 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ?
             // ---- epilogue of this tile (stores drain while the next tile's MFMAs run) ----
             const int tile = (int)blockIdx.x + tile_i * (int)gridDim.x;
             const int per_z = tiles_m * tiles_n;
-            const int z = tile / per_z, rem = tile - z * per_z;
-            const int m0 = (rem / tiles_n) * BM, n0 = (rem % tiles_n) * BN;
+            int z = tile / per_z, rem = tile - z * per_z;
+            int m0 = (rem / tiles_n) * BM, n0 = (rem % tiles_n) * BN;
+            if (g.sub_from > 0) {
+                const int big = g.sub_from + (tile >> 2), q = tile & 3;
+                z = 0;
+                m0 = (2 * (big / g.parent_tn) + (q >> 1)) * BM;
+                n0 = (2 * (big % g.parent_tn) + (q & 1)) * BN;
+            }
             bool vec = false;
             if constexpr (epi_has_store4<Epi>::value) vec = epi.vec_ok() && n0 + BN <= g.N;
             if constexpr (epi_is_gated<Epi>::value) {
@@ -562,9 +577,10 @@ inline bool dma_ok(const Args& g) {
 }
 
 template <int BM, int BN, class Epi, int NS = 3, int ABLATE = 0, int NW = 8, int A_MODE = A_PLAIN>
-inline void launch_dma(hipStream_t st, const Args& g, int batch, const Epi& epi) {
+inline void launch_dma(hipStream_t st, const Args& g, int batch, const Epi& epi, int total_override = -1) {
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-    const int total = tiles_m * tiles_n * batch;
+    const int total = total_override >= 0 ? total_override : tiles_m * tiles_n * batch;
+    if (total == 0) return;
     // resident workgroups per CU by LDS (NS stages of (BM+BN) x 128 B), 8 waves each
     constexpr int lds_bytes = NS * (BM + BN) * 128;
     constexpr int by_waves = 16 / NW;   // 4 waves per SIMD
@@ -615,8 +631,25 @@ inline void launch(hipStream_t st, const Args& g, int batch, const Epi& epi) {
             // (tools/gemm_ab.py, M=11008: N=256 K=512 35.3 vs 38.8 us, K=768 49.2 vs 54.8 us)
             if (g.N <= 256)
                 launch_dma<64, 64, Epi, 3, 0, 4>(st, g, batch, epi);
-            else if (blocks(128, 128) >= 512)
-                launch_dma<128, 128, Epi, 2>(st, g, batch, epi);
+            else if (blocks(128, 128) >= 512) {
+                // 512 resident workgroups walk the tiles in rounds.  When the last round holds only a few tiles (QKV at
+                // the bench shape: 1032 = 2 * 512 + 8) those run alone on their CUs for a whole tile time; they are
+                // cut out of this launch and run as 64x64 tiles on 4 waves instead (4 small workgroups per tile).
+                const int total = (int)blocks(128, 128);
+                const int rem = total % 512;
+                bool split = false;
+                if constexpr (!epi_is_gated<Epi>::value) {
+                    if (batch == 1 && rem > 0 && rem <= 64) {
+                        split = true;
+                        launch_dma<128, 128, Epi, 2>(st, g, batch, epi, total - rem);
+                        Args r = g;
+                        r.sub_from = total - rem;
+                        r.parent_tn = (g.N + 127) / 128;
+                        launch_dma<64, 64, Epi, 3, 0, 4>(st, r, 1, epi, 4 * rem);
+                    }
+                }
+                if (!split) launch_dma<128, 128, Epi, 2>(st, g, batch, epi);
+            }
             else
                 launch_dma<128, 64, Epi, 3>(st, g, batch, epi);
             return;
@@ -642,6 +675,8 @@ inline Args make(const float* A, int64_t lda, const float* B, int64_t ldb, int M
     g.Fr = 1;
     g.Cin = 4;
     g.zeros = nullptr;
+    g.sub_from = 0;
+    g.parent_tn = 0;
     return g;
 }
 
