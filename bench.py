@@ -31,7 +31,8 @@ BYTES_PER_SAMPLE_API = 6.02   # units 256*4 + f0 4 + volume 4 in, 5
 PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 DOMINANT = "u2c_gemm_linear"          # kernel family with the largest share of the step (profiles/)
 DOMINANT_KERNEL = ("gemm::kernel_dma (persistent LDS-DMA fp32 MFMA 32x32x2 GEMM): Linear / 1x1-conv layers of unit2ctrl - "
-                   "128x128 tiles on 8 waves for QKV, pw1+GLU and the head, 64x64 tiles on 4 waves for the N=256 layers")
+                   "128x128 tiles on 8 waves for QKV (its last 8 tiles as 64x64 tiles in a second kernel), pw1+GLU and the head, "
+                   "64x64 tiles on 4 waves for the N=256 layers")
 
 
 def measured_traffic():
