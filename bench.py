@@ -29,17 +29,29 @@ HOP = 512
 SR = 44100
 BYTES_PER_SAMPLE_API = 6.02   # units 256*4 + f0 4 + volume 4 in, 512*4 + 4 out per frame
 PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
-DOMINANT = "u2c_gemm_linear"          # kernel family with the largest share of the step (profiles/)
-DOMINANT_KERNEL = ("gemm::kernel_dma (persistent LDS-DMA fp32 MFMA 32x32x2 GEMM): Linear / 1x1-conv layers of unit2ctrl - "
-                   "128x128 tiles on 8 waves for QKV (its last 8 tiles as 64x64 tiles in a second kernel), pw1+GLU and the head, "
-                   "64x64 tiles on 4 waves for the N=256 layers")
+PEAK_MFMA_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+# The two kernel families with the largest shares of the step (profiles/); both are bracketed by HIP events in the timed
+# region and the one that took longer is reported as `roofline`, the other as `roofline_other`.
+#  * ltv_fir: frame-varying FIR on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32).
+#  * u2c_gemm_linear: the control network's Linear layers.  At the bench batch they run the SPLIT-bf16 mode of the DMA GEMM:
+#    every fp32 product is formed from 3 bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulation), so the kernel ISSUES three
+#    times its algorithmic FLOP on the bf16 pipe.  Its roofline entry therefore holds issued bf16 FLOP/s against the bf16
+#    dense peak (the same fraction as algorithmic FLOP/s against peak/3) and carries the algorithmic rate alongside.
+FAMILIES_TIMED = ("ltv_fir", "u2c_gemm_linear")
+KERNEL_LABEL = {
+    "ltv_fir": "ltv_fir_kernel (frame-varying FIR as Toeplitz-block products, fp32 MFMA 16x16x4; three launches per step: "
+               "all-pass 510 taps, source 1022 taps, noise 510 taps)",
+    "u2c_gemm_linear": "gemm::kernel_dma (persistent LDS-DMA GEMM, split-bf16 products = 3 bf16 MFMA 32x32x16 per fp32 "
+                       "product): Linear / 1x1-conv layers of unit2ctrl - 128x128 tiles on 8 waves for QKV (its last 8 "
+                       "tiles as 64x64 tiles in a second kernel), pw1+GLU and the head, 64x64 tiles on 4 waves for the "
+                       "N=256 layers",
+}
 
 
-def measured_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
-    WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH 'HBM'; tools/pmc_traffic.py).  PMC collection
-    needs the profiler around the process, so bench.py reads the last committed measurement instead of taking it
-    live; None when the file is absent."""
+def measured_traffic(family):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in
+    separate runs, FETCH doubled per MI355X_MICROARCH 'HBM'; tools/pmc_traffic.py).  PMC collection needs the profiler
+    around the process, so bench.py reads the last committed measurement instead of taking it live; None when absent."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_per_launch.json")))
     if not files:
@@ -47,10 +59,14 @@ def measured_traffic():
     d = json.load(open(files[-1]))
     tot = n = 0.0
     for k, v in d.items():
+        if family == "ltv_fir":
+            if k.startswith("ltv_fir_kernel"):
+                tot += v["hbm_bytes_per_launch"] * v["launches_sampled"]
+                n += v["launches_sampled"]
         # the Linear layers' instantiations at the bench shape (QKV, pw1+GLU, out-projection / pw2, head); the same
         # kernel template also runs the prenet convs and the filter-synthesis DFTs, which are other families
-        if "kernel_dma" in k and any(t in k for t in ("EpiSplit3", "EpiGlu", "EpiResidual",
-                                                      "kernel_dma<128, 128, gemm::EpiStore")):
+        elif "kernel_dma" in k and any(t in k for t in ("EpiSplit3", "EpiGlu", "EpiResidual",
+                                                        "kernel_dma<128, 128, gemm::EpiStore")):
             tot += v["hbm_bytes_per_launch"] * v["launches_sampled"]
             # per GEMM CALL: the QKV call is two kernels (its 128x128 tiles and the 64x64 remainder of the last round)
             if "kernel_dma<64, 64, EpiSplit3" not in k:
@@ -170,7 +186,7 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    ctx.profile_begin([DOMINANT])          # HIP events around the dominant kernel only (a few per step)
+    ctx.profile_begin(list(FAMILIES_TIMED))  # HIP events around the two largest families only (16 per step)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -181,7 +197,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    dom = ctx.profile_end()[DOMINANT]
+    timed = ctx.profile_end()
     if dist is not None:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -215,13 +231,26 @@ def main():
     torch.cuda.synchronize()
     fam = ctx.profile_end()
     if rank == 0:
-        avg_ms = dom["ms_total"] / dom["launches"]
-        achieved = dom["flops_total"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
-        out["roofline"] = {"kernel": DOMINANT_KERNEL, "bound": "mfma", "achieved": achieved,
-                           "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F32_TFLOPS,
-                           "traffic": measured_traffic(), "avg_launch_ms": avg_ms, "launches": dom["launches"],
-                           "algorithmic_bytes_per_launch": dom["bytes_total"] / dom["launches"],
-                           "algorithmic_flops_per_launch": dom["flops_total"] / dom["launches"]}
+        def roofline_of(name):
+            d = timed[name]
+            avg_ms = d["ms_total"] / d["launches"]
+            alg = d["flops_total"] / d["launches"] / (avg_ms * 1e-3) / 1e12
+            r = {"kernel": KERNEL_LABEL[name], "bound": "mfma", "unit": "TFLOP/s",
+                 "traffic": measured_traffic(name), "avg_launch_ms": avg_ms, "launches": d["launches"],
+                 "ms_per_step": d["ms_total"] / args.steps,
+                 "algorithmic_bytes_per_launch": d["bytes_total"] / d["launches"],
+                 "algorithmic_flops_per_launch": d["flops_total"] / d["launches"]}
+            if name == "u2c_gemm_linear" and args.mode == "synth":
+                r.update({"arithmetic": "split-bf16: 3 bf16 MFMAs per fp32 product, fp32 accumulation",
+                          "achieved": 3.0 * alg, "peak": PEAK_MFMA_BF16_TFLOPS, "frac": 3.0 * alg / PEAK_MFMA_BF16_TFLOPS,
+                          "algorithmic_tflops": alg})
+            else:
+                r.update({"arithmetic": "fp32 MFMA", "achieved": alg, "peak": PEAK_MFMA_F32_TFLOPS,
+                          "frac": alg / PEAK_MFMA_F32_TFLOPS})
+            return r
+        order = sorted(FAMILIES_TIMED, key=lambda f: -timed[f]["ms_total"])
+        out["roofline"] = roofline_of(order[0])
+        out["roofline_other"] = roofline_of(order[1])
         out["kernel_families_ms_per_step"] = {k: round(v["ms_total"] / nb, 4) for k, v in fam.items()}
         out["kernel_families_tflops"] = {k: round(v["flops_total"] / (v["ms_total"] * 1e-3) / 1e12, 2)
                                          for k, v in fam.items() if v["flops_total"] > 0}

@@ -28,6 +28,9 @@ extern "C" int ddsp_gemm_f32(ddsp_ctx* ctx, void* stream, const float* A, int64_
         else if (tile == 13) gemm::launch_dma<128, 128, gemm::EpiStore, 2>(st, g, 1, e);
         else if (tile == 14) gemm::launch_dma<128, 64, gemm::EpiStore, 2>(st, g, 1, e);
         else if (tile == 15) gemm::launch_dma<64, 64, gemm::EpiStore, 3, 0, 4>(st, g, 1, e);   // 4 waves, 64x64
+        else if (tile == 30) gemm::launch_dma<128, 128, gemm::EpiStore, 2, 0, 8, gemm::A_PLAIN, 3>(st, g, 1, e);  // split-bf16 x3 (experiment)
+        else if (tile == 31) gemm::launch_dma<128, 128, gemm::EpiStore, 2, 0, 8, gemm::A_PLAIN, 6>(st, g, 1, e);  // split-bf16 x6 (experiment)
+        else if (tile == 32) gemm::launch_dma<64, 64, gemm::EpiStore, 3, 0, 4, gemm::A_PLAIN, 3>(st, g, 1, e);    // split-bf16 x3, 64x64 / 4 waves
         else if (tile == 16) gemm::launch_dma<64, 128, gemm::EpiStore, 3, 0, 4>(st, g, 1, e);  // 4 waves, 64x128
         else if (tile == 20) gemm::launch_dma<128, 64, gemm::EpiStore, 3, 1>(st, g, 1, e);   // no MFMA (timing only)
         else if (tile == 21) gemm::launch_dma<128, 64, gemm::EpiStore, 3, 2>(st, g, 1, e);   // no DMA (timing only)

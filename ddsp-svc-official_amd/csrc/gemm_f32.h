@@ -45,6 +45,9 @@ struct Args {
     // remainder mode of the DMA kernel (sub_from > 0): tile t of this launch is quadrant t & 3 of the PARENT tiling's tile
     // sub_from + t / 4, the parent tiles being twice as large in both directions and parent_tn of them per row
     int sub_from, parent_tn;
+    // product arithmetic of the DMA kernel: 0 = fp32 MFMA, 3 = split-bf16 (3 bf16 MFMAs per fp32 product, ~4e-6 relative
+    // error per GEMM instead of 3e-7, 1.5-1.8x faster at the control network's shapes); set per call by the caller
+    int math;
 };
 
 constexpr int BK = 32;
@@ -331,7 +334,10 @@ __global__ void __launch_bounds__(64 * NW) kernel(Args g, Epi epi) {
 // k = 16h + s) identically for A and B, which leaves the sum unchanged.
 // NW = 8 waves as a 4(M) x 2(N) grid, or NW = 4 as 2 x 2 (64x64 tiles: four times as many workgroups for the skinny
 // N = 256 layers, whose 128-row tilings leave a third of the CUs without work).
-template <int BM, int BN, class Epi, int NS = 3, int ABLATE = 0, int NW = 8, int A_MODE = A_PLAIN>  // ABLATE bit mask (timing experiments only): 1 no MFMA, 2 no DMA, 4 no epilogue stores, 8 no barrier
+// MATH: 0 = fp32 MFMA (what every caller uses); 3 / 6 = EXPERIMENT (reachable through ddsp_gemm_f32 tiles 30-32 only):
+// each fp32 operand is split into bf16 pieces in registers and the product formed from 3 (hi*hi + hi*lo + lo*hi) or 6
+// bf16 MFMAs (32x32x16) with fp32 accumulation - speed and error of a split-bf16 path, see DESIGN.md section 9.
+template <int BM, int BN, class Epi, int NS = 3, int ABLATE = 0, int NW = 8, int A_MODE = A_PLAIN, int MATH = 0>  // ABLATE bit mask (timing experiments only): 1 no MFMA, 2 no DMA, 4 no epilogue stores, 8 no barrier
 __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ? 4 : 2)) kernel_dma(Args g, Epi epi, int tiles_m, int tiles_n, int total_tiles) {
     constexpr int WGM = NW / 2, WGN = 2;
     constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
@@ -473,6 +479,46 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ?
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j][0] += av[i][0][0] + bv[j][3][3];
+        } else if constexpr (MATH != 0) {
+            // split-bf16 experiment: the lane's 16 k-values form two K=16 steps of 8 values per lane half; A and B use the
+            // same (half, element) slots, so whatever k order the instruction assigns to them the pairs match
+            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+            auto split = [](const f32x4& x0, const f32x4& x1, bf16x8 (&p)[3]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float r = e < 4 ? x0[e] : x1[e - 4];
+#pragma unroll
+                    for (int q = 0; q < (MATH > 3 ? 3 : 2); ++q) {
+                        const __bf16 h = (__bf16)r;
+                        p[q][e] = h;
+                        r -= (float)h;
+                    }
+                }
+            };
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                bf16x8 ap[TM][3], bp[TN][3];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) split(av[i][2 * half], av[i][2 * half + 1], ap[i]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) split(bv[j][2 * half], bv[j][2 * half + 1], bp[j]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        auto mm = [&](int x, int y) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][x], bp[j][y], acc[i][j], 0, 0, 0);
+                        };
+                        if constexpr (MATH > 3) {      // smallest terms first
+                            mm(2, 0);
+                            mm(0, 2);
+                            mm(1, 1);
+                        }
+                        mm(1, 0);
+                        mm(0, 1);
+                        mm(0, 0);
+                    }
+            }
         } else {
 #pragma unroll
             for (int s = 0; s < 16; ++s)
@@ -576,7 +622,7 @@ inline bool dma_ok(const Args& g) {
            g.sA_hi % 4 == 0 && g.sA_lo % 4 == 0 && g.sB_hi % 4 == 0 && g.sB_lo % 4 == 0;
 }
 
-template <int BM, int BN, class Epi, int NS = 3, int ABLATE = 0, int NW = 8, int A_MODE = A_PLAIN>
+template <int BM, int BN, class Epi, int NS = 3, int ABLATE = 0, int NW = 8, int A_MODE = A_PLAIN, int MATH = 0>
 inline void launch_dma(hipStream_t st, const Args& g, int batch, const Epi& epi, int total_override = -1) {
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
     const int total = total_override >= 0 ? total_override : tiles_m * tiles_n * batch;
@@ -588,7 +634,16 @@ inline void launch_dma(hipStream_t st, const Args& g, int batch, const Epi& epi,
     constexpr int per_cu = by_lds < by_waves ? by_lds : by_waves;
     int grid = 256 * per_cu;
     if (grid > total) grid = total;
-    hipLaunchKernelGGL((kernel_dma<BM, BN, Epi, NS, ABLATE, NW, A_MODE>), dim3(grid), dim3(64 * NW), 0, st, g, epi, tiles_m, tiles_n, total);
+    hipLaunchKernelGGL((kernel_dma<BM, BN, Epi, NS, ABLATE, NW, A_MODE, MATH>), dim3(grid), dim3(64 * NW), 0, st, g, epi, tiles_m, tiles_n, total);
+}
+
+// launch_dma with the product arithmetic chosen at run time (Args::math)
+template <int BM, int BN, class Epi, int NS = 3, int NW = 8, int A_MODE = A_PLAIN>
+inline void dma_go(hipStream_t st, const Args& g, int batch, const Epi& epi, int total_override = -1) {
+    if (g.math == 3)
+        launch_dma<BM, BN, Epi, NS, 0, NW, A_MODE, 3>(st, g, batch, epi, total_override);
+    else
+        launch_dma<BM, BN, Epi, NS, 0, NW, A_MODE, 0>(st, g, batch, epi, total_override);
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC, int A_MODE, class Epi, int NW = 4>
@@ -612,14 +667,14 @@ inline void launch(hipStream_t st, const Args& g, int batch, const Epi& epi) {
         // implicit-im2col convs (N = 256): the 4-wave 64x64 DMA tile with one source pointer per tap
         if (dma_ok(g) && g.zeros && g.Cin % 32 == 0 && g.Cin + 32 <= DDSP_ZERO_FLOATS && g.N <= 256 &&
             blocks(64, 64) >= 256) {
-            launch_dma<64, 64, Epi, 3, 0, 4, A_CONV3>(st, g, batch, epi);
+            dma_go<64, 64, Epi, 3, 4, A_CONV3>(st, g, batch, epi);
             return;
         }
     }
     if constexpr (A_KC && B_KC && A_MODE == A_PLAIN) {
         if (dma_ok(g) && g.N <= 256 && blocks(64, 64) >= 256) {
             // skinny layers also at half the bench batch (training, B = 32: 5504 rows -> 344 tiles of 64x64)
-            launch_dma<64, 64, Epi, 3, 0, 4>(st, g, batch, epi);
+            dma_go<64, 64, Epi, 3, 4>(st, g, batch, epi);
             return;
         }
         if (dma_ok(g) && blocks(128, 64) >= 256) {
@@ -630,7 +685,7 @@ inline void launch(hipStream_t st, const Args& g, int batch, const Epi& epi) {
             // workgroups (a third of the CUs idle or doubly loaded), 64x64 gives 688 on 768 slots
             // (tools/gemm_ab.py, M=11008: N=256 K=512 35.3 vs 38.8 us, K=768 49.2 vs 54.8 us)
             if (g.N <= 256)
-                launch_dma<64, 64, Epi, 3, 0, 4>(st, g, batch, epi);
+                dma_go<64, 64, Epi, 3, 4>(st, g, batch, epi);
             else if (blocks(128, 128) >= 512) {
                 // 512 resident workgroups walk the tiles in rounds.  When the last round holds only a few tiles (QKV at
                 // the bench shape: 1032 = 2 * 512 + 8) those run alone on their CUs for a whole tile time; they are
@@ -641,17 +696,17 @@ inline void launch(hipStream_t st, const Args& g, int batch, const Epi& epi) {
                 if constexpr (!epi_is_gated<Epi>::value) {
                     if (batch == 1 && rem > 0 && rem <= 64) {
                         split = true;
-                        launch_dma<128, 128, Epi, 2>(st, g, batch, epi, total - rem);
+                        dma_go<128, 128, Epi, 2>(st, g, batch, epi, total - rem);
                         Args r = g;
                         r.sub_from = total - rem;
                         r.parent_tn = (g.N + 127) / 128;
-                        launch_dma<64, 64, Epi, 3, 0, 4>(st, r, 1, epi, 4 * rem);
+                        dma_go<64, 64, Epi, 3, 4>(st, r, 1, epi, 4 * rem);
                     }
                 }
-                if (!split) launch_dma<128, 128, Epi, 2>(st, g, batch, epi);
+                if (!split) dma_go<128, 128, Epi, 2>(st, g, batch, epi);
             }
             else
-                launch_dma<128, 64, Epi, 3>(st, g, batch, epi);
+                dma_go<128, 64, Epi, 3>(st, g, batch, epi);
             return;
         }
     }
@@ -677,6 +732,7 @@ inline Args make(const float* A, int64_t lda, const float* B, int64_t ldb, int M
     g.zeros = nullptr;
     g.sub_from = 0;
     g.parent_tn = 0;
+    g.math = 0;
     return g;
 }
 

@@ -379,6 +379,8 @@ __global__ void __launch_bounds__(256) glu_kernel(const float* __restrict__ g1, 
 // preparation launch) so that the 31 tap loads are contiguous rows too - in the (512, 31) parameter layout every
 // tap load of a wavefront touches 64 cache lines, which cost more than the convolution itself.
 constexpr int DW_RUN = 32;
+// 3 = split-bf16 products (3 bf16 MFMAs per fp32 product) for the inference GEMMs of the control network; 0 = fp32 MFMA
+constexpr int U2C_INFER_MATH = 3;
 // SILU: apply SiLU (forward) and optionally keep the pre-activation; FLIP: correlate with reversed taps and no
 // bias (the input-gradient of the same convolution).
 template <bool SILU, bool FLIP>
@@ -923,6 +925,9 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
     const int64_t B = in.B, Fr = in.Fr, M = B * Fr, M8 = M * H;
     const int iM = (int)M;
     const size_t n_w1 = (size_t)D * 3 * w.n_unit, n_w2 = (size_t)D * 3 * D, n_wh = (size_t)w.n_out * D;
+    // product arithmetic of the Linear / conv GEMMs (gemm::Args::math): inference uses the split-bf16 mode, the
+    // training forward (activations kept for the backward pass) stays on fp32 MFMA like the backward GEMMs
+    const int lin_math = bf.l[0].pre ? 0 : U2C_INFER_MATH;
     const float* zero_page = nullptr;   // source of the conv taps that fall off an utterance (LDS-DMA conv GEMM)
     if (int rc = ddsp_zero_page(ctx, &zero_page)) return rc;
     // Inference, and enough rows that the Linear layers run the 128x128 DMA tile anyway: GLU is formed inside the pw1
@@ -956,6 +961,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
     // ---- prenet: conv k3 -> GroupNorm(4) -> LeakyReLU -> conv k3 ----
     {
         gemm::Args g = gemm::make(in.units, w.n_unit, bf.w1, 3 * w.n_unit, iM, D, 3 * w.n_unit);
+        g.math = lin_math;
         g.Fr = (int)Fr;
         g.Cin = w.n_unit;
         g.zeros = zero_page;
@@ -971,6 +977,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
     float* x = bf.l[0].x_in;
     {
         gemm::Args g = gemm::make(bf.t2, D, bf.w2, 3 * D, iM, D, 3 * D);
+        g.math = lin_math;
         g.Fr = (int)Fr;
         g.Cin = D;
         g.zeros = zero_page;
@@ -991,6 +998,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
              hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, b.x_in, L.norm_w, L.norm_b, M, b.y));
         {
             gemm::Args g = gemm::make(b.y, D, bf.wqkv + (size_t)l * 3 * INNER * D, D, iM, 3 * INNER, D);
+            g.math = lin_math;
             EpiSplit3 e{{b.q, b.k, b.v}, bf.bqkv + (size_t)l * 3 * INNER};
             PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * 3 * INNER * D, 4.0 * M * (D + 3 * INNER),
                  (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
@@ -1045,6 +1053,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         }
         {
             gemm::Args g = gemm::make(b.attn, INNER, L.out_w, INNER, iM, D, INNER);
+            g.math = lin_math;
             gemm::EpiResidual e{b.x_mid, b.x_in, D, L.out_b};
             PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * D * INNER, 4.0 * M * (INNER + 2 * D),
                  (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
@@ -1054,13 +1063,15 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
              hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, b.x_mid, L.cm_ln_w, L.cm_ln_b, M, b.y2));
         if (fuse_glu) {
             gemm::Args g = gemm::make(b.y2, D, bf.wglu + (size_t)l * 2 * INNER * D, D, iM, 2 * INNER, D);
+            g.math = lin_math;
             EpiGlu e{b.glu, bf.bglu + (size_t)l * 2 * INNER};
             DDSP_REQUIRE(ctx, gemm::dma_ok(g) && ((uintptr_t)b.glu % 16) == 0, "unit2ctrl: fused GLU needs aligned activations");
             PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * 2 * INNER * D, 4.0 * M * (D + INNER),
-                 (gemm::launch_dma<128, 128, EpiGlu, 2>(st, g, 1, e)));
+                 (gemm::dma_go<128, 128, EpiGlu, 2>(st, g, 1, e)));
         } else {
             {
                 gemm::Args g = gemm::make(b.y2, D, L.cm_pw1_w, D, iM, 2 * INNER, D);
+                g.math = lin_math;
                 gemm::EpiStore e{b.g1, 2 * INNER, L.cm_pw1_b, 1, 0, 0};
                 PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * 2 * INNER * D, 4.0 * M * (D + 2 * INNER),
                      (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
@@ -1073,6 +1084,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
                                 dim3(256), 0, st, b.glu, bf.wdw + (size_t)l * DWK * INNER, L.cm_dw_b, (int)B, (int)Fr, b.dwo, b.pre, 1, INNER));
         {
             gemm::Args g = gemm::make(b.dwo, INNER, L.cm_pw2_w, INNER, iM, D, INNER);
+            g.math = lin_math;
             gemm::EpiResidual e{b.x_out, b.x_mid, D, L.cm_pw2_b};
             PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * D * INNER, 4.0 * M * (INNER + 2 * D),
                  (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
@@ -1085,6 +1097,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
                             M, bf.y_final));
     {
         gemm::Args g = gemm::make(bf.y_final, D, bf.wh, D, iM, w.n_out, D);
+        g.math = lin_math;
         gemm::EpiStore e{ctrl, w.n_out, w.head_b, 1, 0, 0};
         PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * w.n_out * D, 4.0 * M * (D + w.n_out),
              (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));

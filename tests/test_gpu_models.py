@@ -270,5 +270,27 @@ def test_full_bench_batch_equals_its_shards(dev, lib_path, name):
             part = model(inp["units"][sl], inp["f0"][sl], inp["volume"][sl], inp["spk_id"][sl], noise=noise[sl])[0]
             assert part.shape == (8, Fr * 512)
             err = rms(part - full[sl])
-            assert err < 2e-5 * scale, (name, lo, err, scale)
+            # The 64-clip batch runs the control network's GEMMs in the split-bf16 mode (3 bf16 MFMAs per fp32 product,
+            # ~4e-6 relative error per GEMM); shards of 8 are below the DMA kernels' size thresholds and run fp32 MFMA.
+            # Measured difference: ~5e-6 RMS on a 0.07-RMS waveform; asserted at a fifth of the 1e-4 north-star gate.
+            assert err < 2e-5 and err < 4e-4 * scale, (name, lo, err, scale)
     assert float(full.abs().max()) > 0 and torch.isfinite(full).all()
+
+
+def test_full_bench_batch_against_oracle(dev, lib_path):
+    """The north-star gate at the bench size itself: CombSub, 64 clips x 172 frames, GPU (split-bf16 GEMMs, fused GLU,
+    DMA convs, 128x128 / 64x64 tiles) against the CPU oracle on identical inputs and injected noise: <= 1e-4 RMS."""
+    model, cfg = synthetic.build_model("CombSub", seed=7)
+    sd = model.state_dict()
+    B, Fr = 64, 172
+    inp = synthetic.make_inputs(901, B, Fr)
+    with torch.no_grad():
+        sig_o, ph_o, (hm_o, nz_o), aux = OS.combsub_forward(sd, cfg, inp["units"], inp["f0"], inp["volume"],
+                                                            inp["spk_id"], infer=True, noise=inp["noise"])
+    model = model.to(dev).eval()
+    d = _to(inp, dev)
+    with torch.no_grad():
+        sig, ph, (hm, nz) = model(d["units"], d["f0"], d["volume"], d["spk_id"], infer=True, noise=d["noise"])
+    errs = (rms(sig.cpu() - sig_o), rms(hm.cpu() - hm_o), rms(nz.cpu() - nz_o))
+    assert max(errs) < GATE, errs
+    assert rms(sig_o) > 1e-3
