@@ -162,6 +162,9 @@ __global__ void __launch_bounds__(256) fir_act_bwd_kernel(int mode, const float*
 
 }  // namespace
 
+// 3 = split-bf16 products for the forward inverse-DFT GEMMs (when they run on the DMA kernel), 0 = fp32 MFMA
+constexpr int FIR_SYNTH_MATH = 3;
+
 extern "C" int ddsp_fir_from_ctrl(ddsp_ctx* ctx, void* stream, int mode, const float* ctrl, int64_t ctrl_ld,
                                   int n_mag, const float* f0_frames, int64_t rows, int sr, float* ir) {
     DDSP_REQUIRE(ctx, ctx && ctrl && ir, "ddsp_fir_from_ctrl: null argument");
@@ -196,7 +199,9 @@ extern "C" int ddsp_fir_from_ctrl(ddsp_ctx* ctx, void* stream, int mode, const f
     DDSP_LAUNCH_CHECK(ctx);
     ddsp_prof_begin(ctx, st, PF_FIR_DFT_GEMM);
 
-    auto run = [&](const gemm::Args& g, const auto& epi) {
+    auto run = [&](gemm::Args g, const auto& epi) {
+        // (split-bf16 products like the control network's inference GEMMs: the taps then carry ~4e-6 relative error)
+        g.math = tap_major ? FIR_SYNTH_MATH : 0;
         if (tap_major)
             gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, epi);
         else
