@@ -32,15 +32,17 @@ PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_MFMA_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 # The two kernel families with the largest shares of the step (profiles/); both are bracketed by HIP events in the timed
 # region and the one that took longer is reported as `roofline`, the other as `roofline_other`.
-#  * ltv_fir: frame-varying FIR on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32).
-#  * u2c_gemm_linear: the control network's Linear layers.  At the bench batch they run the SPLIT-bf16 mode of the DMA GEMM:
-#    every fp32 product is formed from 3 bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulation), so the kernel ISSUES three
-#    times its algorithmic FLOP on the bf16 pipe.  Its roofline entry therefore holds issued bf16 FLOP/s against the bf16
-#    dense peak (the same fraction as algorithmic FLOP/s against peak/3) and carries the algorithmic rate alongside.
+#  * ltv_fir: frame-varying FIR as Toeplitz-block products (v_mfma_f32_16x16x32_bf16, operands split into bf16 hi/lo
+#    planes while they are staged into the LDS).
+#  * u2c_gemm_linear: the control network's Linear layers, the SPLIT-bf16 mode of the DMA GEMM at the bench batch.
+#  In both every fp32 product is formed from 3 bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulation), so the kernel ISSUES
+#  three times its algorithmic FLOP on the bf16 pipe.  The roofline entries therefore hold issued bf16 FLOP/s against the
+#  bf16 dense peak (the same fraction as algorithmic FLOP/s against peak/3) and carry the algorithmic rate alongside.
 FAMILIES_TIMED = ("ltv_fir", "u2c_gemm_linear")
 KERNEL_LABEL = {
-    "ltv_fir": "ltv_fir_kernel (frame-varying FIR as Toeplitz-block products, fp32 MFMA 16x16x4; three launches per step: "
-               "all-pass 510 taps, source 1022 taps, noise 510 taps)",
+    "ltv_fir": "ltv_fir_bf16_kernel (frame-varying FIR as Toeplitz-block products, split-bf16 = 3 bf16 MFMA 16x16x32 per "
+               "fp32 product, operands split while staged into the LDS; three launches per step: all-pass 510 taps, "
+               "source 1022 taps, noise 510 taps)",
     "u2c_gemm_linear": "gemm::kernel_dma (persistent LDS-DMA GEMM, split-bf16 products = 3 bf16 MFMA 32x32x16 per fp32 "
                        "product): Linear / 1x1-conv layers of unit2ctrl - 128x128 tiles on 8 waves for QKV (its last 8 "
                        "tiles as 64x64 tiles in a second kernel), pw1+GLU and the head, 64x64 tiles on 4 waves for the "
@@ -240,7 +242,7 @@ def main():
                  "ms_per_step": d["ms_total"] / args.steps,
                  "algorithmic_bytes_per_launch": d["bytes_total"] / d["launches"],
                  "algorithmic_flops_per_launch": d["flops_total"] / d["launches"]}
-            if name == "u2c_gemm_linear" and args.mode == "synth":
+            if name == "ltv_fir" or args.mode == "synth":
                 r.update({"arithmetic": "split-bf16: 3 bf16 MFMAs per fp32 product, fp32 accumulation",
                           "achieved": 3.0 * alg, "peak": PEAK_MFMA_BF16_TFLOPS, "frac": 3.0 * alg / PEAK_MFMA_BF16_TFLOPS,
                           "algorithmic_tflops": alg})

@@ -18,6 +18,7 @@ DDSP_OK, DDSP_ERR_ARG, DDSP_ERR_HIP, DDSP_ERR_OOM = 0, -1, -2, -3
 COMB_NONE, COMB_SINC, COMB_SINC_GATED = 0, 1, 2
 FIR_ALLPASS, FIR_DYNAMIC, FIR_STATIC = 0, 1, 2
 EXC_AUDIO, EXC_UNIT_NOISE, EXC_GENERATE = 0, 1, 2
+FIR_FP32, FIR_SPLIT_BF16 = 0, 3   # ddsp_ltv_fir `math` (include/ddsp_amd.h)
 
 _c = ctypes
 _vp, _i64, _u64, _int, _f32 = _c.c_void_p, _c.c_int64, _c.c_uint64, _c.c_int, _c.c_float
@@ -78,7 +79,7 @@ SIGNATURES = {
                                   _c.POINTER(_i64), _c.POINTER(_f32), _int, _i64, _i64, _vp]),
     "ddsp_unit2ctrl_bwd": (_int, [_vp, _vp, _c.POINTER(U2CWeights), _vp, _vp, _vp, _vp, _vp, _i64,
                                   _c.POINTER(_i64), _c.POINTER(_f32), _int, _i64, _i64, _vp, _c.POINTER(U2CWeights), _vp]),
-    "ddsp_ltv_fir": (_int, [_vp, _vp, _vp, _int, _u64, _vp, _i64, _i64, _int, _int, _vp, _vp, _vp]),
+    "ddsp_ltv_fir": (_int, [_vp, _vp, _vp, _int, _u64, _vp, _i64, _i64, _int, _int, _vp, _vp, _vp, _int]),
 }
 
 _lib = None
@@ -266,14 +267,15 @@ class Context:
         return ir
 
     # -- a7 ------------------------------------------------------------------------------------
-    def ltv_fir(self, audio, ir, B, Fr, hop, excitation=EXC_AUDIO, noise_seed=0, add_in=None, want_out=True):
-        """Returns (filtered | None, filtered + add_in | None)."""
+    def ltv_fir(self, audio, ir, B, Fr, hop, excitation=EXC_AUDIO, noise_seed=0, add_in=None, want_out=True,
+                math=FIR_FP32):
+        """Returns (filtered | None, filtered + add_in | None).  math: FIR_FP32 or FIR_SPLIT_BF16 (inference)."""
         n = ir.shape[-1]
         mk = lambda: torch.empty(B, Fr * hop, device=ir.device, dtype=torch.float32)
         out = mk() if want_out else None
         out_sum = mk() if add_in is not None else None
         self.call("ddsp_ltv_fir", _ptr(audio), int(excitation), int(noise_seed), _ptr(ir), B, Fr, int(hop), int(n),
-                  _ptr(add_in), _ptr(out), _ptr(out_sum))
+                  _ptr(add_in), _ptr(out), _ptr(out_sum), int(math))
         return out, out_sum
 
 

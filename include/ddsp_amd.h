@@ -79,13 +79,19 @@ int ddsp_fir_from_ctrl(ddsp_ctx* ctx, void* stream, int mode, const float* ctrl,
  *                                 noise_seed (perf mode: the CPU mt19937 stream cannot be reproduced on a GPU).
  * out (B,T) or NULL receives the filtered signal; out_sum (B,T) or NULL receives filtered + add_in
  * (fuses `harmonic + noise`, ddsp/vocoder.py:548); add_in and out_sum are given together.
+ * math: DDSP_FIR_FP32 = products on the fp32 matrix pipe (training forward, tight-tolerance checks);
+ *       DDSP_FIR_SPLIT_BF16 = every fp32 product formed from three bf16 matrix products (hi*hi + lo*hi + hi*lo,
+ *       fp32 accumulation, ~4e-6 relative error; the inference path).  Filters too long for that kernel's
+ *       staging fall back to the fp32 kernel.
  * Requires hop == 512 and n even, 32 <= n <= 2046. */
+#define DDSP_FIR_FP32 0
+#define DDSP_FIR_SPLIT_BF16 3
 #define DDSP_EXC_AUDIO 0
 #define DDSP_EXC_UNIT_NOISE 1
 #define DDSP_EXC_GENERATE 2
 int ddsp_ltv_fir(ddsp_ctx* ctx, void* stream, const float* audio, int excitation, uint64_t noise_seed,
                  const float* ir, int64_t B, int64_t Fr, int hop, int n, const float* add_in, float* out,
-                 float* out_sum);
+                 float* out_sum, int math);
 
 
 /* ---- a4: unit -> control network ---------------------------------------------------------- */

@@ -5,6 +5,7 @@ import torch
 
 from conftest import rms
 from oracle import dsp as O
+import hipddsp
 
 pytestmark = pytest.mark.gpu
 
@@ -114,6 +115,33 @@ def test_ltv_fir_small_vs_direct(ctx, dev, n, Fr, B):
     assert rms(want_fft.double() - want64) < 1e-6           # the oracle's two forms agree
     assert rms(got.double() - want64) < 1e-6
     assert (got.double() - want64).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("n,Fr,B", [(510, 6, 2), (1022, 6, 2), (510, 7, 1), (1022, 1, 2), (64, 3, 1), (32, 2, 1), (254, 13, 3),
+                                    (1022, 25, 2), (1534, 9, 1), (2046, 5, 1)])
+def test_ltv_fir_split_bf16_vs_direct(ctx, dev, n, Fr, B):
+    """The inference arithmetic (three bf16 matrix products per fp32 product, include/ddsp_amd.h DDSP_FIR_SPLIT_BF16)
+    against the fp64 direct form.  Tolerance: 1e-5 of the output's rms / 3e-5 of its peak, i.e. an order of magnitude
+    inside the 1e-4 waveform gate; n = 1534 and 2046 exceed that kernel's staging and must fall back to fp32 products."""
+    rng = np.random.Generator(np.random.PCG64(n + Fr))
+    x = torch.from_numpy(rng.uniform(-1, 1, size=(B, Fr * HOP)).astype(np.float32))
+    ir = torch.from_numpy((rng.standard_normal((B, Fr, n)) / np.sqrt(n)).astype(np.float32))
+    add = torch.from_numpy(rng.standard_normal((B, Fr * HOP)).astype(np.float32))
+    want64 = O.ltv_fir_direct(x, ir)
+    got, got_sum = ctx.ltv_fir(x.to(dev), ir.to(dev), B, Fr, HOP, add_in=add.to(dev), math=hipddsp.FIR_SPLIT_BF16)
+    got = got.cpu()
+    scale, peak = rms(want64), float(want64.abs().max())
+    assert rms(got.double() - want64) < 1e-5 * scale
+    assert (got.double() - want64).abs().max() < 3e-5 * peak
+    assert torch.equal(got_sum.cpu(), add + got)
+    if n >= 1534:
+        ref, _ = ctx.ltv_fir(x.to(dev), ir.to(dev), B, Fr, HOP)
+        assert torch.equal(ref.cpu(), got)
+    # both excitation modes feed the same samples to either arithmetic
+    for exc, src in ((1, torch.from_numpy(rng.random((B, Fr * HOP), dtype=np.float32)).to(dev)), (2, None)):
+        a, _ = ctx.ltv_fir(src, ir.to(dev), B, Fr, HOP, excitation=exc, noise_seed=5)
+        b_, _ = ctx.ltv_fir(src, ir.to(dev), B, Fr, HOP, excitation=exc, noise_seed=5, math=hipddsp.FIR_SPLIT_BF16)
+        assert (a - b_).abs().max() < 3e-5 * float(a.abs().max())
 
 
 def test_ltv_fir_full_size_and_fusions(ctx, dev):
