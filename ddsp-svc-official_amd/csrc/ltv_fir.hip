@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(64 * 2 * SEG) ltv_fir_kernel(FirArgs g) {
 }
 
 
-// ---- forward, split-bf16 products (inference) -----------------------------------------------------------------
+// ---- forward, split-bf16 products ---------------------------------------------------------------------------
 // Same sum as ltv_fir_kernel, with each fp32 product formed from three bf16 MFMAs (hi*hi + lo*hi + hi*lo, fp32
 // accumulate; ~4e-6 relative error) on v_mfma_f32_16x16x32_bf16: one instruction covers a column
 // shift of 32 samples, A_Q[i][r] = ir[32Q + c + i - r], B_Q[r][j] = xw_m[16*(J0+j) - 32Q + r], r = 0..31.
@@ -241,8 +241,13 @@ __global__ void __launch_bounds__(64 * 2 * SEG) ltv_fir_kernel(FirArgs g) {
 //   * the filter row reversed, S[y] = ir[n-1-(y-FPL)], as dwords of two neighbours in two copies one tap apart
 //     (C0[d] = S[2d],S[2d+1]; C1[d] = S[2d+1],S[2d+2]) for hi and lo: a lane's 8 taps start at an offset whose parity is
 //     fixed by its row i, so it reads 4 dwords from "its" copy.  The copies sit 16 banks apart (fd = 16 mod 32).
-// The matrix pipe needs 48 cycles per (tile, Q); the LDS reads (8 ds_read_b32 + 2 ds_read_b128 per tile and Q, 24 LDS
-// cycles, shared by the four SIMDs) are what bounds the product loop; a wave that owns NT = 2 tiles reads A once for both.
+// The matrix pipe needs 48 cycles per (tile, Q); the LDS reads (8 ds_read_b32 + 2 ds_read_b128 per tile and Q = 24 LDS
+// cycles, shared by the four SIMDs) bound the product loop.
+// Two kernels share the staging and product code:
+//   * ltv_fir_bf16_kernel<SEGB>: one block = SEGB segments, stage everything, barrier, multiply (any shape);
+//   * ltv_fir_bf16_march_kernel<SEGB, SW>: one block walks a long run of segments of one batch row, SEGB at a time, with
+//     the frames in an LDS ring: 2*SEGB wavefronts multiply while SEGB*SW others stage the SEGB frames the next step
+//     adds, so no frame is staged twice and staging hides behind the products (large batches).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -250,8 +255,8 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 constexpr int FPL = 48, FPR = 80;      // zero taps either side of the reversed filter row
 constexpr int XPAD = 272;              // zero samples either side of a frame image
 constexpr int XPLANE = (2 * HOP + 2 * XPAD) / 2;  // dwords per image plane (784 = 16 mod 32)
-constexpr int FKMAX = 6;              // filter dwords per lane and staging pass
-constexpr int FIR_BF16_CFG_6 = 2, FIR_BF16_CFG_4 = 1;  // default block shapes: <6 segments, 1 tile per wave>, <4, 1>
+constexpr int FKMAX = 6;               // filter dwords per lane and staging pass
+constexpr int STAGE_FILTER = 1, STAGE_IMAGE = 2;
 
 struct FirBfArgs {
     const float* audio;
@@ -263,8 +268,10 @@ struct FirBfArgs {
     float* out_sum;
     int Fr, n;
     int Q_lo, Q_hi;   // shift range of the filter (units of 32 samples)
-    int nfr, m_off;   // frames staged per block, first staged frame relative to the block's first segment
+    int nfr, m_off;   // frames a step needs (SEGB + extra), first of them relative to the step's first segment
     int fd;           // dwords per filter copy
+    int chunk;        // march kernel: segments per block (multiple of SEGB)
+    int ring;         // march kernel: frames in the LDS ring (nfr + SEGB)
 };
 
 __device__ __forceinline__ int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
@@ -276,28 +283,14 @@ __device__ __forceinline__ void split_bf16(float x, uint32_t& hi, uint32_t& lo) 
     lo = (uint32_t)__builtin_bit_cast(uint16_t, l);
 }
 
-template <int SEGB, int NT>
-__global__ void __launch_bounds__(64 * (2 * SEGB / NT), (SEGB <= 4 ? 4 : 3)) ltv_fir_bf16_kernel(FirBfArgs g) {
-    extern __shared__ __align__(16) uint32_t ldsw[];
-    constexpr int NWAVE = 2 * SEGB / NT;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y, s0 = blockIdx.x * SEGB;
+// One wavefront stages frame m of batch row b into fr = [C0h | C1h | C0l | C1l | Xh | Xl].  Every global load of a part
+// is issued before its first use; LDS accesses of one wave are ordered, so the caller's barrier is the only one.
+__device__ __forceinline__ void fir_bf16_stage(const FirBfArgs& g, int b, int m, uint32_t* fr, int lane, int parts) {
+    const int fd = g.fd;
     const int64_t T = (int64_t)g.Fr * HOP;
-    const int c = g.n / 2, fd = g.fd;
-    const int fstride = 4 * fd + 2 * XPLANE;   // dwords per staged frame: C0h | C1h | C0l | C1l | Xh | Xl
-    const int m_lo = s0 + g.m_off;
-
-    for (int f = wave; f < g.nfr; f += NWAVE) {
-        const int m = m_lo + f;
-        if (m < 0 || m > g.Fr) continue;
-        uint32_t* fr = ldsw + (size_t)f * fstride;
-        // Every global load of the frame is issued before the first one is consumed (one memory latency per frame):
-        // the filter row reversed, as (S[2d+1], S[2d]) pairs plus S[2d+2], and 16 input samples per lane.
-        const int mi = m < g.Fr ? m : g.Fr - 1;
-        const float* src = g.ir + ((int64_t)b * g.Fr + mi) * g.n;
+    f32x4 x[4];
+    if (parts & STAGE_IMAGE) {
         const int64_t tb = (int64_t)HOP * (m - 1);
-        f32x4 x[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int64_t t = tb + 4 * (lane + 64 * k);
@@ -315,7 +308,11 @@ __global__ void __launch_bounds__(64 * (2 * SEGB / NT), (SEGB <= 4 ? 4 : 3)) ltv
                 }
             }
         }
-        // (1) filter copies, FKMAX dwords per lane and pass
+    }
+    if (parts & STAGE_FILTER) {
+        // the row reversed, as (S[2d+1], S[2d]) pairs plus S[2d+2]
+        const int mi = m < g.Fr ? m : g.Fr - 1;
+        const float* src = g.ir + ((int64_t)b * g.Fr + mi) * g.n;
         for (int base = 0; base < fd; base += 64 * FKMAX) {
             float2 pr[FKMAX];
             float nx[FKMAX];
@@ -342,155 +339,206 @@ __global__ void __launch_bounds__(64 * (2 * SEGB / NT), (SEGB <= 4 ? 4 : 3)) ltv
                 }
             }
         }
-        // (2) windowed input, hi and lo planes
-        {
-            uint32_t* xh = fr + 4 * fd;
-            uint32_t* xl = xh + XPLANE;
-            for (int i = lane; i < XPAD / 2; i += 64) {
-                xh[i] = 0u;
-                xl[i] = 0u;
-                xh[XPAD / 2 + HOP + i] = 0u;
-                xl[XPAD / 2 + HOP + i] = 0u;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int z = 4 * (lane + 64 * k);
-                uint32_t h[4], l[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int zz = z + e;
-                    const float w = (zz < HOP) ? (float)zz * (1.0f / HOP) : (float)(2 * HOP - zz) * (1.0f / HOP);
-                    split_bf16(x[k][e] * w, h[e], l[e]);
-                }
-                *(u32x2*)(xh + (XPAD + z) / 2) = (u32x2){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
-                *(u32x2*)(xl + (XPAD + z) / 2) = (u32x2){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
-            }
-        }
     }
-    __syncthreads();
-
-    // wave w owns NT consecutive 256-sample tiles starting at column J0
-    const int J0 = HOPC * s0 + 16 * NT * wave;
-    if (16 * (int64_t)J0 >= T) return;
-    const int li = lane & 15, lk = lane >> 4;
-    f32x4 acc[NT][3];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int x = 0; x < 3; ++x) acc[t][x] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // A: taps S[y0 + e], y0 = FPL + n-1 - c - li + 8*lk - 32Q  ->  copy (y0 & 1), dword (y0 >> 1)
-    const int y00 = FPL + g.n - 1 - c - li + 8 * lk;
-    const int a_off = (y00 & 1) * fd + (y00 >> 1);
-    // B: samples XPAD + 16*(J0 + 16t + li) - tb + 8*lk - 32Q  (tb = 512(m-1))
-    for (int f = 0; f < g.nfr; ++f) {
-        const int m = m_lo + f;
-        if (m < 0 || m > g.Fr) continue;
-        const uint32_t* fr = ldsw + (size_t)f * fstride;
-        const int zt0 = 16 * J0 - HOP * (m - 1);   // frame-relative position of the wave's first output
-        int ta[NT], tbq[NT];
-        int Qa = g.Q_hi + 1, Qb = g.Q_lo - 1;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int zt = zt0 + 256 * t;
-            ta[t] = -floor_div(1023 - zt, 32);      // ceil((zt - 1023) / 32)
-            tbq[t] = floor_div(zt + 271, 32);
-            if (ta[t] < g.Q_lo) ta[t] = g.Q_lo;
-            if (tbq[t] > g.Q_hi) tbq[t] = g.Q_hi;
-            if (16 * (int64_t)(J0 + 16 * t) >= T) tbq[t] = ta[t] - 1;   // tile past the end of the signal
-            if (ta[t] <= tbq[t]) {
-                if (ta[t] < Qa) Qa = ta[t];
-                if (tbq[t] > Qb) Qb = tbq[t];
-            }
+    if (parts & STAGE_IMAGE) {
+        uint32_t* xh = fr + 4 * fd;
+        uint32_t* xl = xh + XPLANE;
+        for (int i = lane; i < XPAD / 2; i += 64) {
+            xh[i] = 0u;
+            xl[i] = 0u;
+            xh[XPAD / 2 + HOP + i] = 0u;
+            xl[XPAD / 2 + HOP + i] = 0u;
         }
-        const uint32_t* ah = fr + a_off;
-        const uint32_t* al = ah + 2 * fd;
-        const uint32_t* bh = fr + 4 * fd + (XPAD + zt0) / 2 + 8 * li + 4 * lk;
-        const uint32_t* bl = bh + XPLANE;
-        if constexpr (NT == 1) {
-            // one tile per wave: [Qa, Qb] is the tile's own range.  Three operand sets in rotation, reads of shift Q+2
-            // issued before the MFMAs of shift Q (prefetch indices clamp to Qb: a repeated read, never a stray one).
-            struct Ops { u32x4 ah, al, bh, bl; };
-            auto fetch = [&](int Q, Ops& o) {
-                const uint32_t* pa = ah - 16 * Q;
-                const uint32_t* pl = al - 16 * Q;
-                o.ah = (u32x4){pa[0], pa[1], pa[2], pa[3]};
-                o.al = (u32x4){pl[0], pl[1], pl[2], pl[3]};
-                o.bh = *(const u32x4*)(bh - 16 * Q);
-                o.bl = *(const u32x4*)(bl - 16 * Q);
-            };
-            auto mm = [&](const Ops& o) {
-                const bf16x8 a_h = __builtin_bit_cast(bf16x8, o.ah), a_l = __builtin_bit_cast(bf16x8, o.al);
-                const bf16x8 b_h = __builtin_bit_cast(bf16x8, o.bh), b_l = __builtin_bit_cast(bf16x8, o.bl);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_h, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, b_h, acc[0][1], 0, 0, 0);
-                acc[0][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_l, acc[0][2], 0, 0, 0);
-            };
-            auto upto = [&](int Q) { return Q < Qb ? Q : Qb; };
-            if (Qa <= Qb) {
-                Ops o0, o1, o2;
-                fetch(Qa, o0);
-                fetch(upto(Qa + 1), o1);
-                int Q = Qa;
-                for (; Q + 2 <= Qb; Q += 3) {
-                    fetch(Q + 2, o2);
-                    mm(o0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                    fetch(upto(Q + 3), o0);
-                    mm(o1);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                    fetch(upto(Q + 4), o1);
-                    mm(o2);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                }
-                if (Q <= Qb) mm(o0);
-                if (Q + 1 <= Qb) mm(o1);
-            }
-        } else {
-            for (int Q = Qa; Q <= Qb; ++Q) {
-                const uint32_t* pa = ah - 16 * Q;
-                const uint32_t* pl = al - 16 * Q;
-                const u32x4 AH = {pa[0], pa[1], pa[2], pa[3]};
-                const u32x4 AL = {pl[0], pl[1], pl[2], pl[3]};
-                const bf16x8 ahv = __builtin_bit_cast(bf16x8, AH), alv = __builtin_bit_cast(bf16x8, AL);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    if (Q < ta[t] || Q > tbq[t]) continue;
-                    const bf16x8 bhv = __builtin_bit_cast(bf16x8, *(const u32x4*)(bh + 128 * t - 16 * Q));
-                    const bf16x8 blv = __builtin_bit_cast(bf16x8, *(const u32x4*)(bl + 128 * t - 16 * Q));
-                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahv, bhv, acc[t][0], 0, 0, 0);
-                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alv, bhv, acc[t][1], 0, 0, 0);
-                    acc[t][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahv, blv, acc[t][2], 0, 0, 0);
-                }
-            }
-        }
-    }
+        for (int k = 0; k < 4; ++k) {
+            const int z = 4 * (lane + 64 * k);
+            uint32_t h[4], l[4];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (16 * (int64_t)(J0 + 16 * t) >= T) continue;
-        const f32x4 o = acc[t][0] + (acc[t][1] + acc[t][2]);
-        const int64_t u = (int64_t)b * T + 16 * (int64_t)(J0 + 16 * t + li) + 4 * lk;
-        if (g.out) *(f32x4*)(g.out + u) = o;
-        if (g.out_sum) {
-            const f32x4 ad = *(const f32x4*)(g.add_in + u);
-            *(f32x4*)(g.out_sum + u) = ad + o;
+            for (int e = 0; e < 4; ++e) {
+                const int zz = z + e;
+                const float w = (zz < HOP) ? (float)zz * (1.0f / HOP) : (float)(2 * HOP - zz) * (1.0f / HOP);
+                split_bf16(x[k][e] * w, h[e], l[e]);
+            }
+            *(u32x2*)(xh + (XPAD + z) / 2) = (u32x2){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+            *(u32x2*)(xl + (XPAD + z) / 2) = (u32x2){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
         }
     }
 }
 
-template <int SEGB, int NT>
+// acc += contribution of staged frame m (at fr) to the 256-sample tile whose first column is J0.
+// a_off: the lane's filter offset (copy and dword for Q = 0), lb = 8*li + 4*lk its image offset.  J0, m wave-uniform.
+__device__ __forceinline__ void fir_bf16_products(const FirBfArgs& g, const uint32_t* fr, int m, int J0, int a_off, int lb,
+                                                  f32x4 (&acc)[3]) {
+    const int fd = g.fd;
+    const int zt = 16 * J0 - HOP * (m - 1);   // frame-relative position of the tile's first output
+    int Qa = -floor_div(1023 - zt, 32);       // ceil((zt - 1023) / 32): shifts that reach the frame's 1024 samples
+    int Qb = floor_div(zt + 271, 32);
+    if (Qa < g.Q_lo) Qa = g.Q_lo;
+    if (Qb > g.Q_hi) Qb = g.Q_hi;
+    if (Qa > Qb) return;
+    const uint32_t* ah = fr + a_off;
+    const uint32_t* al = ah + 2 * fd;
+    const uint32_t* bh = fr + 4 * fd + (XPAD + zt) / 2 + lb;
+    const uint32_t* bl = bh + XPLANE;
+    // Three operand sets in rotation, reads of shift Q+2 issued before the MFMAs of shift Q (prefetch indices clamp to
+    // Qb: a repeated read, never a stray one).
+    struct Ops { u32x4 ah, al, bh, bl; };
+    auto fetch = [&](int Q, Ops& o) {
+        const uint32_t* pa = ah - 16 * Q;
+        const uint32_t* pl = al - 16 * Q;
+        o.ah = (u32x4){pa[0], pa[1], pa[2], pa[3]};
+        o.al = (u32x4){pl[0], pl[1], pl[2], pl[3]};
+        o.bh = *(const u32x4*)(bh - 16 * Q);
+        o.bl = *(const u32x4*)(bl - 16 * Q);
+    };
+    auto mm = [&](const Ops& o) {
+        const bf16x8 a_h = __builtin_bit_cast(bf16x8, o.ah), a_l = __builtin_bit_cast(bf16x8, o.al);
+        const bf16x8 b_h = __builtin_bit_cast(bf16x8, o.bh), b_l = __builtin_bit_cast(bf16x8, o.bl);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_h, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, b_h, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_l, acc[2], 0, 0, 0);
+    };
+    auto upto = [&](int Q) { return Q < Qb ? Q : Qb; };
+    Ops o0, o1, o2;
+    fetch(Qa, o0);
+    fetch(upto(Qa + 1), o1);
+    int Q = Qa;
+    for (; Q + 2 <= Qb; Q += 3) {
+        fetch(Q + 2, o2);
+        mm(o0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        fetch(upto(Q + 3), o0);
+        mm(o1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        fetch(upto(Q + 4), o1);
+        mm(o2);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    }
+    if (Q <= Qb) mm(o0);
+    if (Q + 1 <= Qb) mm(o1);
+}
+
+// C/D map of the 16x16 MFMA: col = lane & 15, row = 4*(lane >> 4) + reg  ->  one float4 per lane
+__device__ __forceinline__ void fir_bf16_store(const FirBfArgs& g, int b, int J0, int li, int lk, const f32x4 (&acc)[3]) {
+    const int64_t T = (int64_t)g.Fr * HOP;
+    const f32x4 o = acc[0] + (acc[1] + acc[2]);
+    const int64_t u = (int64_t)b * T + 16 * (int64_t)(J0 + li) + 4 * lk;
+    if (g.out) *(f32x4*)(g.out + u) = o;
+    if (g.out_sum) {
+        const f32x4 ad = *(const f32x4*)(g.add_in + u);
+        *(f32x4*)(g.out_sum + u) = ad + o;
+    }
+}
+
+template <int SEGB>
+__global__ void __launch_bounds__(64 * 2 * SEGB, (SEGB <= 4 ? 4 : 3)) ltv_fir_bf16_kernel(FirBfArgs g) {
+    extern __shared__ __align__(16) uint32_t ldsw[];
+    constexpr int NWAVE = 2 * SEGB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, s0 = blockIdx.x * SEGB;
+    const int fstride = 4 * g.fd + 2 * XPLANE;   // dwords per staged frame
+    const int m_lo = s0 + g.m_off;
+
+    for (int f = wave; f < g.nfr; f += NWAVE) {
+        const int m = m_lo + f;
+        if (m < 0 || m > g.Fr) continue;         // the product loop skips these frames too
+        fir_bf16_stage(g, b, m, ldsw + (size_t)f * fstride, lane, STAGE_FILTER | STAGE_IMAGE);
+    }
+    __syncthreads();
+
+    const int J0 = HOPC * s0 + 16 * wave;        // wave w owns the 256-sample tile starting at column J0
+    if (J0 >= HOPC * g.Fr) return;
+    const int li = lane & 15, lk = lane >> 4;
+    // A: taps S[y0 + e], y0 = FPL + n-1 - c - li + 8*lk - 32Q  ->  copy (y0 & 1), dword (y0 >> 1)
+    const int y00 = FPL + g.n - 1 - g.n / 2 - li + 8 * lk;
+    const int a_off = (y00 & 1) * g.fd + (y00 >> 1);
+    f32x4 acc[3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) acc[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < g.nfr; ++f) {
+        const int m = m_lo + f;
+        if (m < 0 || m > g.Fr) continue;
+        fir_bf16_products(g, ldsw + (size_t)f * fstride, m, J0, a_off, 8 * li + 4 * lk, acc);
+    }
+    fir_bf16_store(g, b, J0, li, lk, acc);
+}
+
+template <int SEGB, int SW>
+__global__ void __launch_bounds__(64 * (2 + SW) * SEGB) ltv_fir_bf16_march_kernel(FirBfArgs g) {
+    extern __shared__ __align__(16) uint32_t ldsw[];
+    constexpr int NCOMP = 2 * SEGB, NWAVE = (2 + SW) * SEGB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    const int hop0 = blockIdx.x * g.chunk;
+    const int hop_end = hop0 + g.chunk < g.Fr ? hop0 + g.chunk : g.Fr;
+    const int fstride = 4 * g.fd + 2 * XPLANE;
+    const int m_base = hop0 + g.m_off;           // ring slot of frame m: (m - m_base) mod ring
+    auto slot = [&](int m) { return ldsw + (size_t)((m - m_base) % g.ring) * fstride; };
+
+    // prologue: the frames of the first step, spread over all wavefronts
+    for (int f = wave; f < g.nfr; f += NWAVE) {
+        const int m = m_base + f;
+        if (m < 0 || m > g.Fr) continue;
+        fir_bf16_stage(g, b, m, slot(m), lane, STAGE_FILTER | STAGE_IMAGE);
+    }
+    __syncthreads();
+
+    const int li = lane & 15, lk = lane >> 4;
+    const int y00 = FPL + g.n - 1 - g.n / 2 - li + 8 * lk;
+    const int a_off = (y00 & 1) * g.fd + (y00 >> 1);
+    for (int s0 = hop0; s0 < hop_end; s0 += SEGB) {
+        if (wave >= NCOMP) {
+            // staging wavefronts: frame j of the SEGB frames the next step adds (part = filter / image when SW == 2)
+            const int sw = wave - NCOMP;
+            const int m = s0 + g.m_off + g.nfr + sw / SW;
+            if (s0 + SEGB < hop_end && m >= 0 && m <= g.Fr)
+                fir_bf16_stage(g, b, m, slot(m), lane, SW == 1 ? (STAGE_FILTER | STAGE_IMAGE) : (sw % SW ? STAGE_IMAGE : STAGE_FILTER));
+        } else {
+            const int J0 = HOPC * s0 + 16 * wave;
+            if (J0 < HOPC * hop_end) {
+                f32x4 acc[3];
+#pragma unroll
+                for (int x = 0; x < 3; ++x) acc[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int f = 0; f < g.nfr; ++f) {
+                    const int m = s0 + g.m_off + f;
+                    if (m < 0 || m > g.Fr) continue;
+                    fir_bf16_products(g, slot(m), m, J0, a_off, 8 * li + 4 * lk, acc);
+                }
+                fir_bf16_store(g, b, J0, li, lk, acc);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int SEGB>
 int launch_fir_bf16(ddsp_ctx* ctx, hipStream_t st, FirBfArgs g, int64_t B, int64_t Fr, size_t lds_bytes) {
     static bool attr_set = false;
     if (!attr_set) {
-        DDSP_HIP(ctx, hipFuncSetAttribute((const void*)ltv_fir_bf16_kernel<SEGB, NT>,
+        DDSP_HIP(ctx, hipFuncSetAttribute((const void*)ltv_fir_bf16_kernel<SEGB>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     dim3 grid((unsigned)((Fr + SEGB - 1) / SEGB), (unsigned)B);
-    hipLaunchKernelGGL((ltv_fir_bf16_kernel<SEGB, NT>), grid, dim3(64 * (2 * SEGB / NT)), lds_bytes, st, g);
+    hipLaunchKernelGGL((ltv_fir_bf16_kernel<SEGB>), grid, dim3(64 * 2 * SEGB), lds_bytes, st, g);
+    return DDSP_OK;
+}
+
+template <int SEGB, int SW>
+int launch_fir_bf16_march(ddsp_ctx* ctx, hipStream_t st, FirBfArgs g, int64_t B, int nchunks, size_t lds_bytes) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        DDSP_HIP(ctx, hipFuncSetAttribute((const void*)ltv_fir_bf16_march_kernel<SEGB, SW>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((ltv_fir_bf16_march_kernel<SEGB, SW>), dim3((unsigned)nchunks, (unsigned)B),
+                       dim3(64 * (2 + SW) * SEGB), lds_bytes, st, g);
     return DDSP_OK;
 }
 
@@ -662,7 +710,7 @@ extern "C" int ddsp_ltv_fir(ddsp_ctx* ctx, void* stream, const float* audio, int
                             const float* ir, int64_t B, int64_t Fr, int hop, int n, const float* add_in, float* out,
                             float* out_sum, int math) {
     DDSP_REQUIRE(ctx, ctx && ir && (out || out_sum), "ddsp_ltv_fir: null argument");
-    DDSP_REQUIRE(ctx, math == 0 || math == 3 || (math >= 31 && math <= 36), "ddsp_ltv_fir: math must be 0 (fp32) or 3 (split-bf16)");
+    DDSP_REQUIRE(ctx, math == 0 || math == 3 || (math >= 31 && math <= 36) || (math >= 41 && math <= 44), "ddsp_ltv_fir: math must be 0 (fp32) or 3 (split-bf16)");
     DDSP_REQUIRE(ctx, excitation >= 0 && excitation <= 2, "ddsp_ltv_fir: unknown excitation");
     DDSP_REQUIRE(ctx, (excitation == DDSP_EXC_GENERATE) || audio, "ddsp_ltv_fir: audio is null");
     DDSP_REQUIRE(ctx, (out_sum == nullptr) == (add_in == nullptr), "ddsp_ltv_fir: out_sum and add_in go together");
@@ -697,30 +745,71 @@ extern "C" int ddsp_ltv_fir(ddsp_ctx* ctx, void* stream, const float* audio, int
         const int extra = (c - 1) / HOP + 1 - g.m_off + 1;  // frames staged beyond the block's own segments
         g.fd = ((n + FPL + FPR) / 2 + 4 + 15) / 32 * 32 + 16;
         const size_t per_frame = (size_t)(4 * g.fd + 2 * XPLANE) * sizeof(uint32_t);
-        int cfg = math == 3 ? 0 : math - 30;   // 31..34: block shapes for tools/fir_bf16_check.py
+        g.chunk = 0;
+        g.ring = 0;
+        DDSP_HIP(ctx, hipSetDevice(ctx->device));
+        // (a) marching blocks when every CU can own a long run of segments: block shape by LDS, <segments per step,
+        //     staging waves per frame>.  math 41..44 force a shape (tools/fir_bf16_check.py).
+        {
+            static const int mseg[5] = {0, 3, 3, 4, 4}, msw[5] = {0, 1, 2, 1, 2};
+            int mc = (math >= 41 && math <= 44) ? math - 40 : 0;
+            if (math == 3) {
+                for (int cand = 4; cand >= 1 && mc == 0; --cand)   // prefer 4 segments per step, two staging waves per frame
+                    if ((size_t)(2 * mseg[cand] + extra) * per_frame <= 160 * 1024 && msw[cand] == 2) mc = cand;
+            }
+            if (mc != 0) {
+                const int segb = mseg[mc];
+                g.nfr = segb + extra;
+                g.ring = g.nfr + segb;
+                const size_t lds_bytes = (size_t)g.ring * per_frame;
+                // blocks: about one per CU, each at least four steps long
+                int nchunks = B >= 256 ? 1 : (int)(256 / B);
+                const int max_chunks = (int)(Fr / (4 * segb));
+                if (nchunks > max_chunks) nchunks = max_chunks;
+                const bool worth = nchunks >= 1 && B * nchunks >= 128;
+                if (lds_bytes <= 160 * 1024 && (worth || math != 3) && nchunks >= 1) {
+                    g.chunk = (int)((Fr + nchunks - 1) / nchunks);
+                    g.chunk = (g.chunk + segb - 1) / segb * segb;
+                    nchunks = (int)((Fr + g.chunk - 1) / g.chunk);
+                    ddsp_prof_begin(ctx, (hipStream_t)stream, PF_LTV_FIR);
+                    int rc;
+                    switch (mc) {
+                        case 1: rc = launch_fir_bf16_march<3, 1>(ctx, (hipStream_t)stream, g, B, nchunks, lds_bytes); break;
+                        case 2: rc = launch_fir_bf16_march<3, 2>(ctx, (hipStream_t)stream, g, B, nchunks, lds_bytes); break;
+                        case 3: rc = launch_fir_bf16_march<4, 1>(ctx, (hipStream_t)stream, g, B, nchunks, lds_bytes); break;
+                        default: rc = launch_fir_bf16_march<4, 2>(ctx, (hipStream_t)stream, g, B, nchunks, lds_bytes); break;
+                    }
+                    if (rc != DDSP_OK) return rc;
+                    ddsp_prof_end(ctx, (hipStream_t)stream, alg_flops, alg_bytes);
+                    DDSP_LAUNCH_CHECK(ctx);
+                    return DDSP_OK;
+                }
+            }
+        }
+        // (b) one block per group of segments.  math 31..34 force a shape, 35 / 36 run staging only (measurement aid).
+        int cfg = (math >= 31 && math <= 36) ? math - 30 : 0;
         static const int seg_of[5] = {0, 4, 6, 7, 5};
-        if (cfg >= 5) {   // 35 / 36: staging only (no products) in shapes 1 / 2 - a measurement aid, output is zero
+        if (cfg >= 5) {
             cfg -= 4;
             g.Q_lo = 1;
             g.Q_hi = 0;
         }
         // two resident 4-segment blocks per CU (one stages while the other multiplies) beat one 6-segment block
         if (cfg == 0)
-            cfg = ((size_t)(4 + extra) * per_frame <= 80 * 1024)    ? FIR_BF16_CFG_4
-                  : ((size_t)(6 + extra) * per_frame <= 160 * 1024) ? FIR_BF16_CFG_6
-                                                                    : FIR_BF16_CFG_4;
+            cfg = ((size_t)(4 + extra) * per_frame <= 80 * 1024)    ? 1
+                  : ((size_t)(6 + extra) * per_frame <= 160 * 1024) ? 2
+                                                                    : 1;
         const int segb = seg_of[cfg];
         g.nfr = segb + extra;
         const size_t lds_bytes = (size_t)g.nfr * per_frame;
         if (lds_bytes <= 160 * 1024) {
-            DDSP_HIP(ctx, hipSetDevice(ctx->device));
             ddsp_prof_begin(ctx, (hipStream_t)stream, PF_LTV_FIR);
             int rc;
             switch (cfg) {
-                case 1: rc = launch_fir_bf16<4, 1>(ctx, (hipStream_t)stream, g, B, Fr, lds_bytes); break;
-                case 2: rc = launch_fir_bf16<6, 1>(ctx, (hipStream_t)stream, g, B, Fr, lds_bytes); break;
-                case 3: rc = launch_fir_bf16<7, 1>(ctx, (hipStream_t)stream, g, B, Fr, lds_bytes); break;
-                default: rc = launch_fir_bf16<5, 1>(ctx, (hipStream_t)stream, g, B, Fr, lds_bytes); break;
+                case 1: rc = launch_fir_bf16<4>(ctx, (hipStream_t)stream, g, B, Fr, lds_bytes); break;
+                case 2: rc = launch_fir_bf16<6>(ctx, (hipStream_t)stream, g, B, Fr, lds_bytes); break;
+                case 3: rc = launch_fir_bf16<7>(ctx, (hipStream_t)stream, g, B, Fr, lds_bytes); break;
+                default: rc = launch_fir_bf16<5>(ctx, (hipStream_t)stream, g, B, Fr, lds_bytes); break;
             }
             if (rc != DDSP_OK) return rc;
             ddsp_prof_end(ctx, (hipStream_t)stream, alg_flops, alg_bytes);

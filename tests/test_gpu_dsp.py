@@ -144,6 +144,27 @@ def test_ltv_fir_split_bf16_vs_direct(ctx, dev, n, Fr, B):
         assert (a - b_).abs().max() < 3e-5 * float(a.abs().max())
 
 
+@pytest.mark.parametrize("B,Fr,n", [(130, 17, 64), (64, 40, 254), (128, 13, 1022), (43, 61, 510)])
+def test_ltv_fir_split_bf16_marching_blocks(ctx, dev, B, Fr, n):
+    """Large batches take the kernel whose blocks walk along a batch row with the frames in an LDS ring (one or several
+    runs per row, ragged last run / last step): same result as the fp32-product kernel within the split-bf16 error, in
+    all three excitation modes and with the fused sum."""
+    g = torch.Generator().manual_seed(B + Fr)
+    x = (torch.rand(B, Fr * HOP, generator=g) * 2 - 1).to(dev)
+    ir = (torch.randn(B, Fr, n, generator=g) / n ** 0.5).to(dev)
+    add = torch.randn(B, Fr * HOP, generator=g).to(dev)
+    ref, _ = ctx.ltv_fir(x, ir, B, Fr, HOP)
+    got, got_sum = ctx.ltv_fir(x, ir, B, Fr, HOP, add_in=add, math=hipddsp.FIR_SPLIT_BF16)
+    peak = float(ref.abs().max())
+    assert (got - ref).abs().max() < 3e-5 * peak
+    assert rms((got - ref).cpu()) < 1e-5 * rms(ref.cpu())
+    assert torch.equal(got_sum, add + got)
+    for exc, src in ((1, torch.rand(B, Fr * HOP, generator=g).to(dev)), (2, None)):
+        a, _ = ctx.ltv_fir(src, ir, B, Fr, HOP, excitation=exc, noise_seed=11)
+        b_, _ = ctx.ltv_fir(src, ir, B, Fr, HOP, excitation=exc, noise_seed=11, math=hipddsp.FIR_SPLIT_BF16)
+        assert (a - b_).abs().max() < 3e-5 * float(a.abs().max())
+
+
 def test_ltv_fir_full_size_and_fusions(ctx, dev):
     B, Fr, n = 4, 172, 1022
     rng = np.random.Generator(np.random.PCG64(77))
