@@ -62,7 +62,7 @@ def measured_traffic(family):
     tot = n = 0.0
     for k, v in d.items():
         if family == "ltv_fir":
-            if k.startswith("ltv_fir_kernel"):
+            if k.startswith("ltv_fir_kernel") or "ltv_fir_bf16" in k:
                 tot += v["hbm_bytes_per_launch"] * v["launches_sampled"]
                 n += v["launches_sampled"]
         # the Linear layers' instantiations at the bench shape (QKV, pw1+GLU, out-projection / pw2, head); the same
