@@ -365,23 +365,13 @@ __device__ __forceinline__ void fir_bf16_stage(const FirBfArgs& g, int b, int m,
     }
 }
 
-// acc += contribution of staged frame m (at fr) to the 256-sample tile whose first column is J0.
-// a_off: the lane's filter offset (copy and dword for Q = 0), lb = 8*li + 4*lk its image offset.  J0, m wave-uniform.
-__device__ __forceinline__ void fir_bf16_products(const FirBfArgs& g, const uint32_t* fr, int m, int J0, int a_off, int lb,
-                                                  f32x4 (&acc)[3]) {
-    const int fd = g.fd;
-    const int zt = 16 * J0 - HOP * (m - 1);   // frame-relative position of the tile's first output
-    int Qa = -floor_div(1023 - zt, 32);       // ceil((zt - 1023) / 32): shifts that reach the frame's 1024 samples
-    int Qb = floor_div(zt + 271, 32);
-    if (Qa < g.Q_lo) Qa = g.Q_lo;
-    if (Qb > g.Q_hi) Qb = g.Q_hi;
+// Product loops.  ah / al: the lane's filter pointers for Q = 0 (hi, lo), bh / bl: its image pointers for Q = 0.
+// Three operand sets in rotation, reads of shift Q+2 issued before the MFMAs of shift Q (prefetch indices clamp to Qb:
+// a repeated read, never a stray one).  Qa, Qb wave-uniform.
+// One tile:
+__device__ __forceinline__ void fir_bf16_run1(const uint32_t* ah, const uint32_t* al, const uint32_t* bh, const uint32_t* bl,
+                                              int Qa, int Qb, f32x4 (&acc)[3]) {
     if (Qa > Qb) return;
-    const uint32_t* ah = fr + a_off;
-    const uint32_t* al = ah + 2 * fd;
-    const uint32_t* bh = fr + 4 * fd + (XPAD + zt) / 2 + lb;
-    const uint32_t* bl = bh + XPLANE;
-    // Three operand sets in rotation, reads of shift Q+2 issued before the MFMAs of shift Q (prefetch indices clamp to
-    // Qb: a repeated read, never a stray one).
     struct Ops { u32x4 ah, al, bh, bl; };
     auto fetch = [&](int Q, Ops& o) {
         const uint32_t* pa = ah - 16 * Q;
@@ -419,6 +409,94 @@ __device__ __forceinline__ void fir_bf16_products(const FirBfArgs& g, const uint
     }
     if (Q <= Qb) mm(o0);
     if (Q + 1 <= Qb) mm(o1);
+}
+// Two neighbouring tiles (the second 256 samples = 128 dwords further on) sharing the filter operand: 4 + 4 LDS read
+// instructions (32 LDS cycles) for 6 MFMAs instead of 2 x (4 + 2) (48 cycles).
+__device__ __forceinline__ void fir_bf16_run2(const uint32_t* ah, const uint32_t* al, const uint32_t* bh, const uint32_t* bl,
+                                              int Qa, int Qb, f32x4 (&acc0)[3], f32x4 (&acc1)[3]) {
+    if (Qa > Qb) return;
+    struct Ops { u32x4 ah, al, bh0, bl0, bh1, bl1; };
+    auto fetch = [&](int Q, Ops& o) {
+        const uint32_t* pa = ah - 16 * Q;
+        const uint32_t* pl = al - 16 * Q;
+        o.ah = (u32x4){pa[0], pa[1], pa[2], pa[3]};
+        o.al = (u32x4){pl[0], pl[1], pl[2], pl[3]};
+        o.bh0 = *(const u32x4*)(bh - 16 * Q);
+        o.bl0 = *(const u32x4*)(bl - 16 * Q);
+        o.bh1 = *(const u32x4*)(bh + 128 - 16 * Q);
+        o.bl1 = *(const u32x4*)(bl + 128 - 16 * Q);
+    };
+    auto mm = [&](const Ops& o) {
+        const bf16x8 a_h = __builtin_bit_cast(bf16x8, o.ah), a_l = __builtin_bit_cast(bf16x8, o.al);
+        const bf16x8 b_h0 = __builtin_bit_cast(bf16x8, o.bh0), b_l0 = __builtin_bit_cast(bf16x8, o.bl0);
+        const bf16x8 b_h1 = __builtin_bit_cast(bf16x8, o.bh1), b_l1 = __builtin_bit_cast(bf16x8, o.bl1);
+        acc0[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_h0, acc0[0], 0, 0, 0);
+        acc1[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_h1, acc1[0], 0, 0, 0);
+        acc0[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, b_h0, acc0[1], 0, 0, 0);
+        acc1[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, b_h1, acc1[1], 0, 0, 0);
+        acc0[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_l0, acc0[2], 0, 0, 0);
+        acc1[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_l1, acc1[2], 0, 0, 0);
+    };
+    auto upto = [&](int Q) { return Q < Qb ? Q : Qb; };
+    Ops o0, o1, o2;
+    fetch(Qa, o0);
+    fetch(upto(Qa + 1), o1);
+    int Q = Qa;
+    for (; Q + 2 <= Qb; Q += 3) {
+        fetch(Q + 2, o2);
+        mm(o0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        fetch(upto(Q + 3), o0);
+        mm(o1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        fetch(upto(Q + 4), o1);
+        mm(o2);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+    }
+    if (Q <= Qb) mm(o0);
+    if (Q + 1 <= Qb) mm(o1);
+}
+
+// Shift range of frame m for the 256-sample tile whose first output sits at frame-relative position zt
+__device__ __forceinline__ void fir_bf16_range(const FirBfArgs& g, int zt, int& Qa, int& Qb) {
+    Qa = -floor_div(1023 - zt, 32);       // ceil((zt - 1023) / 32): shifts that reach the frame's 1024 samples
+    Qb = floor_div(zt + 271, 32);
+    if (Qa < g.Q_lo) Qa = g.Q_lo;
+    if (Qb > g.Q_hi) Qb = g.Q_hi;
+}
+
+// acc += contribution of staged frame m (at fr) to the 256-sample tile whose first column is J0.
+// a_off: the lane's filter offset (copy and dword for Q = 0), lb = 8*li + 4*lk its image offset.  J0, m wave-uniform.
+__device__ __forceinline__ void fir_bf16_products(const FirBfArgs& g, const uint32_t* fr, int m, int J0, int a_off, int lb,
+                                                  f32x4 (&acc)[3]) {
+    const int fd = g.fd;
+    const int zt = 16 * J0 - HOP * (m - 1);   // frame-relative position of the tile's first output
+    int Qa, Qb;
+    fir_bf16_range(g, zt, Qa, Qb);
+    const uint32_t* ah = fr + a_off;
+    const uint32_t* bh = fr + 4 * fd + (XPAD + zt) / 2 + lb;
+    fir_bf16_run1(ah, ah + 2 * fd, bh, bh + XPLANE, Qa, Qb, acc);
+}
+
+// The same for the two tiles J0 and J0 + 16 (one segment): shifts that only one of them needs run as single-tile loops
+// either side of the shared range (the second tile's range is the first one's moved up by 8 shifts, then clipped).
+__device__ __forceinline__ void fir_bf16_products2(const FirBfArgs& g, const uint32_t* fr, int m, int J0, int a_off, int lb,
+                                                   f32x4 (&acc0)[3], f32x4 (&acc1)[3]) {
+    const int fd = g.fd;
+    const int zt = 16 * J0 - HOP * (m - 1);
+    int a0, b0, a1, b1;
+    fir_bf16_range(g, zt, a0, b0);
+    fir_bf16_range(g, zt + 256, a1, b1);
+    const uint32_t* ah = fr + a_off;
+    const uint32_t* al = ah + 2 * fd;
+    const uint32_t* bh = fr + 4 * fd + (XPAD + zt) / 2 + lb;
+    const uint32_t* bl = bh + XPLANE;
+    fir_bf16_run1(ah, al, bh, bl, a0, b0 < a1 - 1 ? b0 : a1 - 1, acc0);
+    fir_bf16_run2(ah, al, bh, bl, a1, b0, acc0, acc1);
+    fir_bf16_run1(ah, al, bh + 128, bl + 128, b0 + 1 > a1 ? b0 + 1 : a1, b1, acc1);
 }
 
 // C/D map of the 16x16 MFMA: col = lane & 15, row = 4*(lane >> 4) + reg  ->  one float4 per lane
@@ -467,7 +545,10 @@ __global__ void __launch_bounds__(64 * 2 * SEGB, (SEGB <= 4 ? 4 : 3)) ltv_fir_bf
     fir_bf16_store(g, b, J0, li, lk, acc);
 }
 
-template <int SEGB, int SW>
+// PAIR = false: a product wavefront owns one 256-sample tile.  PAIR = true: two product wavefronts own one segment (two
+// neighbouring tiles sharing the filter operand), one taking the even, the other the odd frames of the step; the odd one
+// hands its partial sums over through the LDS.  Either way 2*SEGB product wavefronts.
+template <int SEGB, int SW, bool PAIR>
 __global__ void __launch_bounds__(64 * (2 + SW) * SEGB) ltv_fir_bf16_march_kernel(FirBfArgs g) {
     extern __shared__ __align__(16) uint32_t ldsw[];
     constexpr int NCOMP = 2 * SEGB, NWAVE = (2 + SW) * SEGB;
@@ -479,6 +560,7 @@ __global__ void __launch_bounds__(64 * (2 + SW) * SEGB) ltv_fir_bf16_march_kerne
     const int fstride = 4 * g.fd + 2 * XPLANE;
     const int m_base = hop0 + g.m_off;           // ring slot of frame m: (m - m_base) mod ring
     auto slot = [&](int m) { return ldsw + (size_t)((m - m_base) % g.ring) * fstride; };
+    f32x4* handover = (f32x4*)(ldsw + (size_t)g.ring * fstride);   // PAIR: [SEGB][2 tiles][64 lanes] partial sums
 
     // prologue: the frames of the first step, spread over all wavefronts
     for (int f = wave; f < g.nfr; f += NWAVE) {
@@ -492,24 +574,48 @@ __global__ void __launch_bounds__(64 * (2 + SW) * SEGB) ltv_fir_bf16_march_kerne
     const int y00 = FPL + g.n - 1 - g.n / 2 - li + 8 * lk;
     const int a_off = (y00 & 1) * g.fd + (y00 >> 1);
     for (int s0 = hop0; s0 < hop_end; s0 += SEGB) {
+        f32x4 acc[PAIR ? 2 : 1][3];
+        const int seg = wave >> 1, odd = wave & 1;          // PAIR: the wave's segment of the step and its share of the frames
+        const int J0 = PAIR ? HOPC * (s0 + seg) : HOPC * s0 + 16 * wave;
+        const bool mine = wave < NCOMP && J0 < HOPC * hop_end;
         if (wave >= NCOMP) {
             // staging wavefronts: frame j of the SEGB frames the next step adds (part = filter / image when SW == 2)
             const int sw = wave - NCOMP;
             const int m = s0 + g.m_off + g.nfr + sw / SW;
             if (s0 + SEGB < hop_end && m >= 0 && m <= g.Fr)
                 fir_bf16_stage(g, b, m, slot(m), lane, SW == 1 ? (STAGE_FILTER | STAGE_IMAGE) : (sw % SW ? STAGE_IMAGE : STAGE_FILTER));
-        } else {
-            const int J0 = HOPC * s0 + 16 * wave;
-            if (J0 < HOPC * hop_end) {
-                f32x4 acc[3];
+        } else if (mine) {
 #pragma unroll
-                for (int x = 0; x < 3; ++x) acc[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < (PAIR ? 2 : 1); ++t)
+#pragma unroll
+                for (int x = 0; x < 3; ++x) acc[t][x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (PAIR) {
+                for (int f = odd; f < g.nfr; f += 2) {
+                    const int m = s0 + g.m_off + f;
+                    if (m < 0 || m > g.Fr) continue;
+                    fir_bf16_products2(g, slot(m), m, J0, a_off, 8 * li + 4 * lk, acc[0], acc[1]);
+                }
+                if (odd) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) handover[(seg * 2 + t) * 64 + lane] = acc[t][0] + (acc[t][1] + acc[t][2]);
+                }
+            } else {
                 for (int f = 0; f < g.nfr; ++f) {
                     const int m = s0 + g.m_off + f;
                     if (m < 0 || m > g.Fr) continue;
-                    fir_bf16_products(g, slot(m), m, J0, a_off, 8 * li + 4 * lk, acc);
+                    fir_bf16_products(g, slot(m), m, J0, a_off, 8 * li + 4 * lk, acc[0]);
                 }
-                fir_bf16_store(g, b, J0, li, lk, acc);
+                fir_bf16_store(g, b, J0, li, lk, acc[0]);
+            }
+        }
+        if constexpr (PAIR) {
+            __syncthreads();
+            if (mine && !odd) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    acc[t][0] += handover[(seg * 2 + t) * 64 + lane];
+                    fir_bf16_store(g, b, J0 + 16 * t, li, lk, acc[t]);
+                }
             }
         }
         __syncthreads();
@@ -529,15 +635,15 @@ int launch_fir_bf16(ddsp_ctx* ctx, hipStream_t st, FirBfArgs g, int64_t B, int64
     return DDSP_OK;
 }
 
-template <int SEGB, int SW>
+template <int SEGB, int SW, bool PAIR>
 int launch_fir_bf16_march(ddsp_ctx* ctx, hipStream_t st, FirBfArgs g, int64_t B, int nchunks, size_t lds_bytes) {
     static bool attr_set = false;
     if (!attr_set) {
-        DDSP_HIP(ctx, hipFuncSetAttribute((const void*)ltv_fir_bf16_march_kernel<SEGB, SW>,
+        DDSP_HIP(ctx, hipFuncSetAttribute((const void*)ltv_fir_bf16_march_kernel<SEGB, SW, PAIR>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((ltv_fir_bf16_march_kernel<SEGB, SW>), dim3((unsigned)nchunks, (unsigned)B),
+    hipLaunchKernelGGL((ltv_fir_bf16_march_kernel<SEGB, SW, PAIR>), dim3((unsigned)nchunks, (unsigned)B),
                        dim3(64 * (2 + SW) * SEGB), lds_bytes, st, g);
     return DDSP_OK;
 }
@@ -710,7 +816,7 @@ extern "C" int ddsp_ltv_fir(ddsp_ctx* ctx, void* stream, const float* audio, int
                             const float* ir, int64_t B, int64_t Fr, int hop, int n, const float* add_in, float* out,
                             float* out_sum, int math) {
     DDSP_REQUIRE(ctx, ctx && ir && (out || out_sum), "ddsp_ltv_fir: null argument");
-    DDSP_REQUIRE(ctx, math == 0 || math == 3 || (math >= 31 && math <= 36) || (math >= 41 && math <= 44), "ddsp_ltv_fir: math must be 0 (fp32) or 3 (split-bf16)");
+    DDSP_REQUIRE(ctx, math == 0 || math == 3 || (math >= 31 && math <= 36) || (math >= 41 && math <= 48), "ddsp_ltv_fir: math must be 0 (fp32) or 3 (split-bf16)");
     DDSP_REQUIRE(ctx, excitation >= 0 && excitation <= 2, "ddsp_ltv_fir: unknown excitation");
     DDSP_REQUIRE(ctx, (excitation == DDSP_EXC_GENERATE) || audio, "ddsp_ltv_fir: audio is null");
     DDSP_REQUIRE(ctx, (out_sum == nullptr) == (add_in == nullptr), "ddsp_ltv_fir: out_sum and add_in go together");
@@ -751,17 +857,21 @@ extern "C" int ddsp_ltv_fir(ddsp_ctx* ctx, void* stream, const float* audio, int
         // (a) marching blocks when every CU can own a long run of segments: block shape by LDS, <segments per step,
         //     staging waves per frame>.  math 41..44 force a shape (tools/fir_bf16_check.py).
         {
-            static const int mseg[5] = {0, 3, 3, 4, 4}, msw[5] = {0, 1, 2, 1, 2};
-            int mc = (math >= 41 && math <= 44) ? math - 40 : 0;
+            static const int mseg[9] = {0, 3, 3, 4, 4, 3, 3, 4, 4}, msw[9] = {0, 1, 2, 1, 2, 1, 2, 1, 2};
+            int mc = (math >= 41 && math <= 48) ? math - 40 : 0;   // 41..44: a tile per product wave, 45..48: a segment per pair
             if (math == 3) {
-                for (int cand = 4; cand >= 1 && mc == 0; --cand)   // prefer 4 segments per step, two staging waves per frame
-                    if ((size_t)(2 * mseg[cand] + extra) * per_frame <= 160 * 1024 && msw[cand] == 2) mc = cand;
+                // measured order (tools/fir_bf16_check.py): paired product waves, 4 segments per step if the ring fits
+                static const int pref[4] = {7, 6, 4, 2};
+                for (int i = 0; i < 4 && mc == 0; ++i) {
+                    const int cand = pref[i];
+                    if ((size_t)(2 * mseg[cand] + extra) * per_frame + (cand > 4 ? 2048 * (size_t)mseg[cand] : 0) <= 160 * 1024) mc = cand;
+                }
             }
             if (mc != 0) {
                 const int segb = mseg[mc];
                 g.nfr = segb + extra;
                 g.ring = g.nfr + segb;
-                const size_t lds_bytes = (size_t)g.ring * per_frame;
+                const size_t lds_bytes = (size_t)g.ring * per_frame + (mc > 4 ? 2048 * (size_t)segb : 0);   // + hand-over area
                 // blocks: about one per CU, each at least four steps long
                 int nchunks = B >= 256 ? 1 : (int)(256 / B);
                 const int max_chunks = (int)(Fr / (4 * segb));
@@ -773,11 +883,16 @@ extern "C" int ddsp_ltv_fir(ddsp_ctx* ctx, void* stream, const float* audio, int
                     nchunks = (int)((Fr + g.chunk - 1) / g.chunk);
                     ddsp_prof_begin(ctx, (hipStream_t)stream, PF_LTV_FIR);
                     int rc;
+                    hipStream_t st = (hipStream_t)stream;
                     switch (mc) {
-                        case 1: rc = launch_fir_bf16_march<3, 1>(ctx, (hipStream_t)stream, g, B, nchunks, lds_bytes); break;
-                        case 2: rc = launch_fir_bf16_march<3, 2>(ctx, (hipStream_t)stream, g, B, nchunks, lds_bytes); break;
-                        case 3: rc = launch_fir_bf16_march<4, 1>(ctx, (hipStream_t)stream, g, B, nchunks, lds_bytes); break;
-                        default: rc = launch_fir_bf16_march<4, 2>(ctx, (hipStream_t)stream, g, B, nchunks, lds_bytes); break;
+                        case 1: rc = launch_fir_bf16_march<3, 1, false>(ctx, st, g, B, nchunks, lds_bytes); break;
+                        case 2: rc = launch_fir_bf16_march<3, 2, false>(ctx, st, g, B, nchunks, lds_bytes); break;
+                        case 3: rc = launch_fir_bf16_march<4, 1, false>(ctx, st, g, B, nchunks, lds_bytes); break;
+                        case 4: rc = launch_fir_bf16_march<4, 2, false>(ctx, st, g, B, nchunks, lds_bytes); break;
+                        case 5: rc = launch_fir_bf16_march<3, 1, true>(ctx, st, g, B, nchunks, lds_bytes); break;
+                        case 6: rc = launch_fir_bf16_march<3, 2, true>(ctx, st, g, B, nchunks, lds_bytes); break;
+                        case 7: rc = launch_fir_bf16_march<4, 1, true>(ctx, st, g, B, nchunks, lds_bytes); break;
+                        default: rc = launch_fir_bf16_march<4, 2, true>(ctx, st, g, B, nchunks, lds_bytes); break;
                     }
                     if (rc != DDSP_OK) return rc;
                     ddsp_prof_end(ctx, (hipStream_t)stream, alg_flops, alg_bytes);

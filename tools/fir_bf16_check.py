@@ -19,7 +19,7 @@ for (B, Fr, n) in [(2, 6, 510), (2, 6, 1022), (1, 7, 510), (2, 1, 1022), (1, 3, 
     ir = torch.randn(B, Fr, n, device=dev) / n ** 0.5
     add = torch.randn(B, Fr * hop, device=dev)
     ref, ref_sum = ctx.ltv_fir(x, ir, B, Fr, hop, add_in=add, math=0)
-    for math in (3, 31, 32, 33, 34, 41, 42, 43, 44):
+    for math in (3, 31, 32, 33, 34, 41, 42, 43, 44, 45, 46, 47, 48):
         got, got_sum = ctx.ltv_fir(x, ir, B, Fr, hop, add_in=add, math=math)
         e = (got - ref).abs().max().item() / ref.abs().max().item()
         es = (got_sum - ref_sum).abs().max().item() / ref.abs().max().item()
@@ -42,7 +42,7 @@ B, Fr = 64, 172
 x = torch.rand(B, Fr * hop, device=dev) * 2 - 1
 for n in (1022, 510):
     ir = torch.randn(B, Fr, n, device=dev) / n ** 0.5
-    for math in (0, 31, 32, 41, 42, 43, 44, 3):
+    for math in (0, 31, 42, 44, 45, 46, 47, 48, 3):
         for _ in range(3):
             ctx.ltv_fir(x, ir, B, Fr, hop, math=math)
         torch.cuda.synchronize()
