@@ -816,7 +816,7 @@ extern "C" int ddsp_ltv_fir(ddsp_ctx* ctx, void* stream, const float* audio, int
                             const float* ir, int64_t B, int64_t Fr, int hop, int n, const float* add_in, float* out,
                             float* out_sum, int math) {
     DDSP_REQUIRE(ctx, ctx && ir && (out || out_sum), "ddsp_ltv_fir: null argument");
-    DDSP_REQUIRE(ctx, math == 0 || math == 3 || (math >= 31 && math <= 36) || (math >= 41 && math <= 48), "ddsp_ltv_fir: math must be 0 (fp32) or 3 (split-bf16)");
+    DDSP_REQUIRE(ctx, math == 0 || math == 3 || (math >= 31 && math <= 36) || (math >= 41 && math <= 48) || (math >= 51 && math <= 58), "ddsp_ltv_fir: math must be 0 (fp32) or 3 (split-bf16)");
     DDSP_REQUIRE(ctx, excitation >= 0 && excitation <= 2, "ddsp_ltv_fir: unknown excitation");
     DDSP_REQUIRE(ctx, (excitation == DDSP_EXC_GENERATE) || audio, "ddsp_ltv_fir: audio is null");
     DDSP_REQUIRE(ctx, (out_sum == nullptr) == (add_in == nullptr), "ddsp_ltv_fir: out_sum and add_in go together");
@@ -859,6 +859,11 @@ extern "C" int ddsp_ltv_fir(ddsp_ctx* ctx, void* stream, const float* audio, int
         {
             static const int mseg[9] = {0, 3, 3, 4, 4, 3, 3, 4, 4}, msw[9] = {0, 1, 2, 1, 2, 1, 2, 1, 2};
             int mc = (math >= 41 && math <= 48) ? math - 40 : 0;   // 41..44: a tile per product wave, 45..48: a segment per pair
+            if (math >= 51 && math <= 58) {   // the same shapes, staging only (no products; output zero): a measurement aid
+                mc = math - 50;
+                g.Q_lo = 1;
+                g.Q_hi = 0;
+            }
             if (math == 3) {
                 // measured order (tools/fir_bf16_check.py): paired product waves, 4 segments per step if the ring fits
                 static const int pref[4] = {7, 6, 4, 2};

@@ -42,7 +42,7 @@ B, Fr = 64, 172
 x = torch.rand(B, Fr * hop, device=dev) * 2 - 1
 for n in (1022, 510):
     ir = torch.randn(B, Fr, n, device=dev) / n ** 0.5
-    for math in (0, 31, 42, 44, 45, 46, 47, 48, 3):
+    for math in (0, 31, 42, 44, 45, 46, 47, 3, 52, 54, 55, 56, 57):
         for _ in range(3):
             ctx.ltv_fir(x, ir, B, Fr, hop, math=math)
         torch.cuda.synchronize()
