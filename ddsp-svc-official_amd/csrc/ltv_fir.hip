@@ -276,11 +276,14 @@ struct FirBfArgs {
 
 __device__ __forceinline__ int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
-__device__ __forceinline__ void split_bf16(float x, uint32_t& hi, uint32_t& lo) {
-    const __bf16 h = (__bf16)x;
-    const __bf16 l = (__bf16)(x - (float)h);
-    hi = (uint32_t)__builtin_bit_cast(uint16_t, h);
-    lo = (uint32_t)__builtin_bit_cast(uint16_t, l);
+// (a, b) -> dwords of two bf16: hi = (bf16(a), bf16(b)), lo = (bf16(a - hi_a), bf16(b - hi_b)), a in the low half.
+// Two values per v_cvt_pk_bf16_f32 (round to nearest even), the hi parts widened back by a shift / a mask.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_bf16_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v){a, b}, bf16x2v));
+    const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v){a - ha, b - hb}, bf16x2v));
 }
 
 // One wavefront stages frame m of batch row b into fr = [C0h | C1h | C0l | C1l | Xh | Xl].  Every global load of a part
@@ -328,14 +331,13 @@ __device__ __forceinline__ void fir_bf16_stage(const FirBfArgs& g, int b, int m,
             for (int k = 0; k < FKMAX; ++k) {
                 const int d = base + 64 * k + lane;
                 if (d < fd) {
-                    uint32_t h[3], l[3];
-                    split_bf16(pr[k].y, h[0], l[0]);
-                    split_bf16(pr[k].x, h[1], l[1]);
-                    split_bf16(nx[k], h[2], l[2]);
-                    fr[d] = h[0] | (h[1] << 16);
-                    fr[fd + d] = h[1] | (h[2] << 16);
-                    fr[2 * fd + d] = l[0] | (l[1] << 16);
-                    fr[3 * fd + d] = l[1] | (l[2] << 16);
+                    uint32_t h0, l0, h1, l1;
+                    split_bf16_pair(pr[k].y, pr[k].x, h0, l0);   // S[2d], S[2d+1]
+                    split_bf16_pair(pr[k].x, nx[k], h1, l1);     // S[2d+1], S[2d+2]
+                    fr[d] = h0;
+                    fr[fd + d] = h1;
+                    fr[2 * fd + d] = l0;
+                    fr[3 * fd + d] = l1;
                 }
             }
         }
@@ -352,15 +354,19 @@ __device__ __forceinline__ void fir_bf16_stage(const FirBfArgs& g, int b, int m,
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int z = 4 * (lane + 64 * k);
-            uint32_t h[4], l[4];
+            float xw[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                // triangular window: passes k = 0, 1 are the rising half (z < hop), k = 2, 3 the falling one
                 const int zz = z + e;
-                const float w = (zz < HOP) ? (float)zz * (1.0f / HOP) : (float)(2 * HOP - zz) * (1.0f / HOP);
-                split_bf16(x[k][e] * w, h[e], l[e]);
+                const float w = (k < 2) ? (float)zz * (1.0f / HOP) : (float)(2 * HOP - zz) * (1.0f / HOP);
+                xw[e] = x[k][e] * w;
             }
-            *(u32x2*)(xh + (XPAD + z) / 2) = (u32x2){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
-            *(u32x2*)(xl + (XPAD + z) / 2) = (u32x2){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+            uint32_t h0, l0, h1, l1;
+            split_bf16_pair(xw[0], xw[1], h0, l0);
+            split_bf16_pair(xw[2], xw[3], h1, l1);
+            *(u32x2*)(xh + (XPAD + z) / 2) = (u32x2){h0, h1};
+            *(u32x2*)(xl + (XPAD + z) / 2) = (u32x2){l0, l1};
         }
     }
 }

@@ -82,7 +82,8 @@ int ddsp_fir_from_ctrl(ddsp_ctx* ctx, void* stream, int mode, const float* ctrl,
  * math: DDSP_FIR_FP32 = products on the fp32 matrix pipe (training forward, tight-tolerance checks);
  *       DDSP_FIR_SPLIT_BF16 = every fp32 product formed from three bf16 matrix products (hi*hi + lo*hi + hi*lo,
  *       fp32 accumulation, ~4e-6 relative error; the inference path).  Filters too long for that kernel's
- *       staging fall back to the fp32 kernel.
+ *       staging fall back to the fp32 kernel.  (Values 31..58 force one block shape of the split-bf16 kernels or
+ *       switch their products off - measurement aids of tools/fir_bf16_check.py, not part of the interface.)
  * Requires hop == 512 and n even, 32 <= n <= 2046. */
 #define DDSP_FIR_FP32 0
 #define DDSP_FIR_SPLIT_BF16 3
