@@ -483,17 +483,27 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ?
             // split-bf16 experiment: the lane's 16 k-values form two K=16 steps of 8 values per lane half; A and B use the
             // same (half, element) slots, so whatever k order the instruction assigns to them the pairs match
             typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+            // two values at a time: one v_cvt_pk_bf16_f32 (round to nearest even) per piece and pair, the piece widened back
+            // by a shift / a mask, the remainders by one packed subtract - 5 vector instructions per pair and piece
+            typedef float f32x2p __attribute__((ext_vector_type(2)));
+            typedef __bf16 bf16x2p __attribute__((ext_vector_type(2)));
+            typedef uint32_t u32x4p __attribute__((ext_vector_type(4)));
             auto split = [](const f32x4& x0, const f32x4& x1, bf16x8 (&p)[3]) {
+                constexpr int NQ = MATH > 3 ? 3 : 2;
+                u32x4p w[3];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float r = e < 4 ? x0[e] : x1[e - 4];
+                for (int d = 0; d < 4; ++d) {
+                    f32x2p r = d < 2 ? (f32x2p){x0[2 * d], x0[2 * d + 1]} : (f32x2p){x1[2 * d - 4], x1[2 * d - 3]};
 #pragma unroll
-                    for (int q = 0; q < (MATH > 3 ? 3 : 2); ++q) {
-                        const __bf16 h = (__bf16)r;
-                        p[q][e] = h;
-                        r -= (float)h;
+                    for (int q = 0; q < NQ; ++q) {
+                        const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2p));
+                        w[q][d] = h;
+                        if (q + 1 < NQ)
+                            r = r - (f32x2p){__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u)};
                     }
                 }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) p[q] = __builtin_bit_cast(bf16x8, w[q]);
             };
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
