@@ -188,7 +188,9 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    ctx.profile_begin(list(FAMILIES_TIMED))  # HIP events around the two largest families only (16 per step)
+    # HIP events around the two largest families only (16 brackets = 32 records per step; created without the system-scope
+    # fence: with default events the brackets cost 0.095 ms per step, now 0.035 ms - measured against a run without them)
+    ctx.profile_begin(list(FAMILIES_TIMED))
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)

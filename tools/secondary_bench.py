@@ -78,6 +78,15 @@ def rt_graph():
 t = timeit(rt_graph, n=50, warm=5)
 out["realtime_block_B1_hip_graph"] = {"ms_per_block": t * 1e3, "block_ms_of_audio": 200.0, "x_realtime": 0.2 / t,
                                       "host_enqueue_ms": host_ms(rt_graph)}
+# the bench batch replayed from a HIP graph: same kernels as CombSub_forward_B64 minus the host's launch gaps, plus what
+# the replay adds (input copies into static tensors, a torch uniform_ draw for the noise instead of the in-kernel one)
+model64, _ = synthetic.build_model("CombSub", seed=1, device=dev)
+inp64 = {k: v.to(dev) for k, v in synthetic.make_inputs(3, B, Fr, with_noise=False).items()}
+gs64 = graphed.GraphedSynth(model64, B, Fr)
+t = timeit(lambda: gs64(inp64["units"], inp64["f0"], inp64["volume"], inp64["spk_id"]))
+t_replay = timeit(lambda: gs64.graph.replay())
+out["CombSub_forward_B64_hip_graph"] = {"ms": t * 1e3, "ms_replay_only": t_replay * 1e3, "samples_per_s": B * Fr * 512 / t,
+                                        "x_realtime": B * Fr * 512 / t / 44100}
 # (the model constructors print a banner line each; the JSON goes to its own file when a path is given)
 if len(sys.argv) > 1:
     json.dump(out, open(sys.argv[1], "w"), indent=1)
