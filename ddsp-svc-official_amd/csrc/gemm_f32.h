@@ -48,6 +48,11 @@ struct Args {
     // product arithmetic of the DMA kernel: 0 = fp32 MFMA, 3 = split-bf16 (3 bf16 MFMAs per fp32 product, ~4e-6 relative
     // error per GEMM instead of 3e-7, 1.5-1.8x faster at the control network's shapes); set per call by the caller
     int math;
+    // optional copy of B for math == 3 on the DMA kernel, same shape and pitch, already split: every group of 8 consecutive
+    // k-values (32 bytes) holds 8 bf16 hi parts then 8 bf16 lo parts (ddsp_presplit_b).  A lane's B fragment is four
+    // 16-byte slots of one row, so slots 2h / 2h+1 ARE the hi / lo operand of half h and the kernel does not split B.
+    // Paths that do not use it (fp32 products, the register-staged kernel) read B.
+    const float* B_split;
 };
 
 constexpr int BK = 32;
@@ -334,9 +339,10 @@ __global__ void __launch_bounds__(64 * NW) kernel(Args g, Epi epi) {
 // k = 16h + s) identically for A and B, which leaves the sum unchanged.
 // NW = 8 waves as a 4(M) x 2(N) grid, or NW = 4 as 2 x 2 (64x64 tiles: four times as many workgroups for the skinny
 // N = 256 layers, whose 128-row tilings leave a third of the CUs without work).
-// MATH: 0 = fp32 MFMA (what every caller uses); 3 / 6 = EXPERIMENT (reachable through ddsp_gemm_f32 tiles 30-32 only):
-// each fp32 operand is split into bf16 pieces in registers and the product formed from 3 (hi*hi + hi*lo + lo*hi) or 6
-// bf16 MFMAs (32x32x16) with fp32 accumulation - speed and error of a split-bf16 path, see DESIGN.md section 9.
+// MATH: 0 = fp32 MFMA; 3 = split-bf16 (Args::math == 3: the inference GEMMs): each fp32 operand is split into bf16 hi and
+// lo pieces in registers and the product formed from 3 bf16 MFMAs (32x32x16: hi*hi + hi*lo + lo*hi) with fp32 accumulation;
+// 7 = the same with B read already split (Args::B_split); 6 = three pieces, 6 MFMAs (ddsp_gemm_f32 tile 31 only).
+// Speed and error: DESIGN.md section 9.
 template <int BM, int BN, class Epi, int NS = 3, int ABLATE = 0, int NW = 8, int A_MODE = A_PLAIN, int MATH = 0>  // ABLATE bit mask (timing experiments only): 1 no MFMA, 2 no DMA, 4 no epilogue stores, 8 no barrier
 __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ? 4 : 2)) kernel_dma(Args g, Epi epi, int tiles_m, int tiles_n, int total_tiles) {
     constexpr int WGM = NW / 2, WGN = 2;
@@ -489,7 +495,7 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ?
             typedef __bf16 bf16x2p __attribute__((ext_vector_type(2)));
             typedef uint32_t u32x4p __attribute__((ext_vector_type(4)));
             auto split = [](const f32x4& x0, const f32x4& x1, bf16x8 (&p)[3]) {
-                constexpr int NQ = MATH > 3 ? 3 : 2;
+                constexpr int NQ = MATH == 6 ? 3 : 2;
                 u32x4p w[3];
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
@@ -511,7 +517,14 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ?
 #pragma unroll
                 for (int i = 0; i < TM; ++i) split(av[i][2 * half], av[i][2 * half + 1], ap[i]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) split(bv[j][2 * half], bv[j][2 * half + 1], bp[j]);
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (MATH == 7) {   // B arrives split (Args::B_split)
+                        bp[j][0] = __builtin_bit_cast(bf16x8, bv[j][2 * half]);
+                        bp[j][1] = __builtin_bit_cast(bf16x8, bv[j][2 * half + 1]);
+                    } else {
+                        split(bv[j][2 * half], bv[j][2 * half + 1], bp[j]);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -519,7 +532,7 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ?
                         auto mm = [&](int x, int y) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][x], bp[j][y], acc[i][j], 0, 0, 0);
                         };
-                        if constexpr (MATH > 3) {      // smallest terms first
+                        if constexpr (MATH == 6) {      // smallest terms first
                             mm(2, 0);
                             mm(0, 2);
                             mm(1, 1);
@@ -650,7 +663,11 @@ inline void launch_dma(hipStream_t st, const Args& g, int batch, const Epi& epi,
 // launch_dma with the product arithmetic chosen at run time (Args::math)
 template <int BM, int BN, class Epi, int NS = 3, int NW = 8, int A_MODE = A_PLAIN>
 inline void dma_go(hipStream_t st, const Args& g, int batch, const Epi& epi, int total_override = -1) {
-    if (g.math == 3)
+    if (g.math == 3 && g.B_split) {
+        Args h = g;
+        h.B = g.B_split;
+        launch_dma<BM, BN, Epi, NS, 0, NW, A_MODE, 7>(st, h, batch, epi, total_override);
+    } else if (g.math == 3)
         launch_dma<BM, BN, Epi, NS, 0, NW, A_MODE, 3>(st, g, batch, epi, total_override);
     else
         launch_dma<BM, BN, Epi, NS, 0, NW, A_MODE, 0>(st, g, batch, epi, total_override);
@@ -743,6 +760,7 @@ inline Args make(const float* A, int64_t lda, const float* B, int64_t ldb, int M
     g.sub_from = 0;
     g.parent_tn = 0;
     g.math = 0;
+    g.B_split = nullptr;
     return g;
 }
 

@@ -76,6 +76,30 @@ __global__ void rdft_w_table_kernel(float* __restrict__ tab, int N, int ld, int 
     }
 }
 
+// dst = src with every group of 8 consecutive floats replaced by 8 bf16 hi parts (16 bytes) and 8 bf16 lo parts (16 bytes):
+// the B operand layout of gemm::Args::B_split.  Same rounding as the in-kernel split (round to nearest even, twice).
+__global__ void presplit_kernel(const float* __restrict__ src, uint32_t* __restrict__ dst, int64_t groups) {
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+    for (int64_t gidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gidx < groups; gidx += (int64_t)gridDim.x * blockDim.x) {
+        const float* s = src + 8 * gidx;
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const float a = s[2 * d], b = s[2 * d + 1];
+            hi[d] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v){a, b}, bf16x2v));
+            const float ha = __builtin_bit_cast(float, hi[d] << 16), hb = __builtin_bit_cast(float, hi[d] & 0xffff0000u);
+            lo[d] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v){a - ha, b - hb}, bf16x2v));
+        }
+        uint32_t* o = dst + 8 * gidx;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            o[d] = hi[d];
+            o[4 + d] = lo[d];
+        }
+    }
+}
+
 }  // namespace
 
 int ddsp_get_table(ddsp_ctx* ctx, hipStream_t st, int kind, int n0, int n1, float** out) {
@@ -87,6 +111,32 @@ int ddsp_get_table(ddsp_ctx* ctx, hipStream_t st, int kind, int n0, int n1, floa
         }
     }
     if (ctx->n_tables >= 64) return ddsp_fail(ctx, DDSP_ERR_OOM, "table cache full", "");
+    if (n1 == 2) {
+        // the tap-major table (n1 == 1) split into bf16 hi/lo groups: B operand of the split-bf16 GEMM (gemm::Args::B_split)
+        float* plain = nullptr;
+        int rc = ddsp_get_table(ctx, st, kind, n0, 1, &plain);
+        if (rc) return rc;
+        if (ctx->n_tables >= 64) return ddsp_fail(ctx, DDSP_ERR_OOM, "table cache full", "");
+        size_t bytes = 0;
+        for (int i = 0; i < ctx->n_tables; ++i)
+            if (ctx->tables[i].dev == plain) bytes = ctx->tables[i].bytes;
+        if (bytes == 0 || bytes % 32 != 0) return ddsp_fail(ctx, DDSP_ERR_ARG, "table cannot be pre-split", "");
+        float* dev = nullptr;
+        hipError_t e = hipMalloc((void**)&dev, bytes);
+        if (e != hipSuccess) return ddsp_fail(ctx, DDSP_ERR_OOM, "table hipMalloc", hipGetErrorString(e));
+        const int64_t groups = (int64_t)(bytes / 32);
+        hipLaunchKernelGGL(presplit_kernel, dim3((unsigned)((groups + 255) / 256 > 2048 ? 2048 : (groups + 255) / 256)), dim3(256), 0,
+                           st, plain, (uint32_t*)dev, groups);
+        DDSP_LAUNCH_CHECK(ctx);
+        ddsp_table& t = ctx->tables[ctx->n_tables++];
+        t.kind = kind;
+        t.n0 = n0;
+        t.n1 = n1;
+        t.dev = dev;
+        t.bytes = bytes;
+        *out = dev;
+        return DDSP_OK;
+    }
     size_t elems = 0;
     switch (kind) {
         case TAB_IRDFT_RE:
