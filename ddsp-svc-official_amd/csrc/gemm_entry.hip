@@ -32,6 +32,12 @@ extern "C" int ddsp_gemm_f32(ddsp_ctx* ctx, void* stream, const float* A, int64_
         else if (tile == 31) gemm::launch_dma<128, 128, gemm::EpiStore, 2, 0, 8, gemm::A_PLAIN, 6>(st, g, 1, e);  // split-bf16 x6 (experiment)
         else if (tile == 32) gemm::launch_dma<64, 64, gemm::EpiStore, 3, 0, 4, gemm::A_PLAIN, 3>(st, g, 1, e);    // split-bf16 x3, 64x64 / 4 waves
         else if (tile == 16) gemm::launch_dma<64, 128, gemm::EpiStore, 3, 0, 4>(st, g, 1, e);  // 4 waves, 64x128
+        else if (tile == 33) gemm::launch_dma<128, 64, gemm::EpiStore, 3, 0, 8, gemm::A_PLAIN, 3>(st, g, 1, e);   // split-bf16 x3, 128x64
+        else if (tile == 34) gemm::launch_dma<64, 128, gemm::EpiStore, 3, 0, 4, gemm::A_PLAIN, 3>(st, g, 1, e);   // split-bf16 x3, 64x128 / 4 waves
+        else if (tile == 35) gemm::launch_dma<128, 128, gemm::EpiStore, 2, 1, 8, gemm::A_PLAIN, 3>(st, g, 1, e);  // 30 without split + MFMA (timing only)
+        else if (tile == 36) gemm::launch_dma<128, 128, gemm::EpiStore, 2, 2, 8, gemm::A_PLAIN, 3>(st, g, 1, e);  // 30 without DMA
+        else if (tile == 37) gemm::launch_dma<128, 128, gemm::EpiStore, 2, 10, 8, gemm::A_PLAIN, 3>(st, g, 1, e); // 30 without DMA and barrier
+        else if (tile == 38) gemm::launch_dma<128, 128, gemm::EpiStore, 2, 14, 8, gemm::A_PLAIN, 3>(st, g, 1, e); // 30: split + MFMA + LDS reads only
         else if (tile == 20) gemm::launch_dma<128, 64, gemm::EpiStore, 3, 1>(st, g, 1, e);   // no MFMA (timing only)
         else if (tile == 21) gemm::launch_dma<128, 64, gemm::EpiStore, 3, 2>(st, g, 1, e);   // no DMA (timing only)
         else if (tile == 22) gemm::launch_dma<128, 64, gemm::EpiStore, 3, 6>(st, g, 1, e);   // no DMA, no stores
