@@ -3,9 +3,11 @@
 CPU restatement of the SOLA splice of the real-time path (reference
 `gui.py:405-430`, windows `gui.py:349-351`), the offline slice cross-fade
 (`main.py:50-57`) and the volume gate (`main.py:111-116`, `gui.py:108-112`).
-No reference test or fixture covers these; pinned only by
-tests/golden/glue_*.npz generated from verbatim numpy/torch expressions in
-tests/golden/make_golden.py.
+The reference has no test of its own for these.  PINNED by tests/golden/ref_gui_stream.npz and
+ref_offline_glue.npz, which tests/golden/make_golden.py (tier e) produced by EXECUTING
+`gui.GUI.audio_callback` (eight blocks, with and without the phase-vocoder splice),
+`gui.SvcDDSP.infer`'s gate and `main.cross_fade`; the older glue_*.npz hold the same
+expressions evaluated inline by the generator.
 """
 import numpy as np
 import torch
@@ -35,6 +37,28 @@ def sola_step(audio, sola_buffer, block, xfade, search, delay):
     fade_in, fade_out = fade_windows(xfade)
     tmp[:xfade] = tmp[:xfade] * fade_in + sola_buffer * fade_out
     return tmp[:-xfade], tmp[-xfade:].clone(), shift
+
+
+def sola_step_phase_vocoder(audio, sola_buffer, block, xfade, search, delay):
+    """The same block with `use_phase_vocoder` (gui.py:417-423): the head is `phase_vocoder(kept tail, new head)`."""
+    tmp = audio[-block - xfade - search - delay: -delay].clone()
+    head = tmp[None, None, : xfade + search]
+    num = F.conv1d(head, sola_buffer[None, None, :])
+    den = torch.sqrt(F.conv1d(head ** 2, torch.ones(1, 1, xfade)) + 1e-8)
+    shift = int(torch.argmax(num[0, 0] / den[0, 0]))
+    tmp = tmp[shift: shift + block + xfade].clone()
+    fade_in, fade_out = fade_windows(xfade)
+    tmp[:xfade] = phase_vocoder(sola_buffer, tmp[:xfade], fade_out, fade_in)
+    return tmp[:-xfade], tmp[-xfade:].clone(), shift
+
+
+def slide_window(window, indata):
+    """ref: gui.py:373-374.  window (N,) float32 numpy, indata (block, channels): shift left by one block and put the
+    mono mix (librosa.to_mono = channel mean) at the end."""
+    block = indata.shape[0]
+    out = np.roll(window, -block)
+    out[-block:] = np.mean(indata.T, axis=0)
+    return out
 
 
 def slice_cross_fade(a, b, idx):

@@ -17,8 +17,12 @@ Tier C (`glue_*.npz`): caller-side expressions of main.py / gui.py (SOLA splice,
 gate) evaluated verbatim on synthetic data.
 Tier D (`glue_frontend.npz`): the reference's `Volume_Extractor.extract` and the alignment tail of
 `Units_Encoder.encode`, see `tier_d`.
+Tier E (`ref_loss.npz`, `ref_train_step.npz`, `ref_gui_stream.npz`, `ref_offline_glue.npz`): G8 / G9 / G10 of SURVEY
+8(c) - the reference's `ddsp/loss.py`, three iterations of its training step, `gui.GUI.audio_callback`,
+`gui.SvcDDSP.infer`'s gate and `main.cross_fade`, all EXECUTED (see `tier_e`).
 """
 import os
+import re
 import sys
 import types
 
@@ -365,8 +369,241 @@ def tier_d():
     save("glue_phase_vocoder.npz", **pv)
 
 
+# ------------------------------------------------------------------------------------------------
+def _fresh_reference(*names):
+    """Drops cached `ddsp*` / named modules and puts /root/reference first on sys.path for the imports that follow."""
+    for k in [k for k in sys.modules if k == "ddsp" or k.startswith("ddsp.") or k in names]:
+        del sys.modules[k]
+    if REF in sys.path:
+        sys.path.remove(REF)
+    sys.path.insert(0, REF)
+
+
+def _spectrogram_placeholder():
+    """torchaudio is not installed: `torchaudio.transforms.Spectrogram(n_fft, hop_length, power=1, normalized=True,
+    center=False)` (the only construction ddsp/loss.py:14 makes) stands on torch.stft as torchaudio documents it
+    (Hann periodic window of n_fft, one-sided, magnitude, divided by sqrt(sum w^2)).  UNPINNED boundary; the loss
+    arithmetic around it (ddsp/loss.py:16-25,37-43) is the reference's own code."""
+    import torch.nn as nn
+
+    class Spectrogram(nn.Module):
+        def __init__(self, n_fft, hop_length, power, normalized, center):
+            super().__init__()
+            assert power == 1 and normalized is True and center is False
+            self.n_fft, self.hop = n_fft, hop_length
+            self.register_buffer("window", torch.hann_window(n_fft), persistent=False)
+
+        def forward(self, x):
+            st = torch.stft(x, self.n_fft, hop_length=self.hop, win_length=self.n_fft, window=self.window,
+                            center=False, onesided=True, return_complex=True)
+            return (st / self.window.pow(2.0).sum().sqrt()).abs()
+
+    sys.modules["torchaudio"].transforms.Spectrogram = Spectrogram
+    sys.modules["torchaudio.transforms"].Spectrogram = Spectrogram
+
+
+def tier_e():
+    """G8 / G9 / G10 of SURVEY 8(c): fixtures produced by EXECUTING the reference's loss, training step and caller
+    glue (not by re-typing their expressions).
+      ref_loss.npz        `ddsp/loss.py` SSSLoss / RSSLoss (Spectrogram placeholder, see above)
+      ref_train_step.npz  three iterations of `solver.py:110-114` on the reference CombSub with `torch.optim.AdamW`
+                          (`train.py:41-45`), reference RSSLoss, injected noise
+      ref_gui_stream.npz  `gui.GUI.audio_callback` (gui.py:367-430) run for eight blocks on an object made with
+                          object.__new__ (no window, no audio device), `svc_model.infer` replaced by a stand-in that
+                          returns prepared model output; with and without `use_phase_vocoder`
+      ref_offline_glue.npz `gui.SvcDDSP.infer`'s volume gate (gui.py:103-112,125-127) with stand-ins for the f0 /
+                          units extractors and the model, and `main.cross_fade` (main.py:50-57) imported from main.py
+    """
+    import contextlib
+    import io
+    import warnings
+    warnings.simplefilter("ignore")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import glue_cases as GC
+    _placeholders()
+    _spectrogram_placeholder()
+
+    # ---- G8 ---------------------------------------------------------------------------------------------------
+    _fresh_reference()
+    import ddsp.loss as RL
+    assert RL.__file__.startswith(REF)
+    xp, xt = GC.loss_signals()
+    g = {}
+    for N in GC.LOSS_SCALES:
+        x = xp.clone().requires_grad_(True)
+        v = RL.SSSLoss(N)(xt, x)
+        v.backward()
+        g[f"sss_{N}"] = v.detach()
+        g[f"sss_gradnorm_{N}"] = x.grad.norm()
+        g[f"sss_grad_{N}"] = x.grad[:, ::97]
+        # fp64 run of the same reference code: the fp32 gradient is ill-conditioned (1/S terms), tests judge against this
+        x64 = xp.double().clone().requires_grad_(True)
+        v64 = RL.SSSLoss(N).double()(xt.double(), x64)
+        v64.backward()
+        g[f"sss64_{N}"] = v64.detach()
+        g[f"sss64_grad_{N}"] = x64.grad[:, ::97]
+        g[f"sss64_gradnorm_{N}"] = x64.grad.norm()
+    crit = RL.RSSLoss(256, 2048, 4, device="cpu")
+    torch.manual_seed(GC.RSS_SEED)
+    x = xp.clone().requires_grad_(True)
+    v = crit(x, xt)
+    v.backward()
+    torch.manual_seed(GC.RSS_SEED)
+    g["rss_scales"] = torch.randint(256, 2048, (4,))
+    g["rss"] = v.detach()
+    g["rss_gradnorm"] = x.grad.norm()
+    g["rss_grad"] = x.grad[:, ::97]
+    save("ref_loss.npz", **g)
+
+    # ---- G9 ---------------------------------------------------------------------------------------------------
+    for k in [k for k in sys.modules if k == "ddsp" or k.startswith("ddsp.")]:
+        del sys.modules[k]
+    sys.path.remove(REF)
+    import synthetic
+    prod, cfg = synthetic.build_model("CombSub", seed=GC.TRAIN_WEIGHT_SEED)
+    sd = {k: v.clone() for k, v in prod.state_dict().items()}
+    _fresh_reference()
+    import ddsp.vocoder as V
+    import ddsp.loss as RL
+    assert V.__file__.startswith(REF) and RL.__file__.startswith(REF)
+    model = V.CombSub(SR, HOP, cfg["n_mag_allpass"], cfg["n_mag_harmonic"], cfg["n_mag_noise"], 256, cfg["n_spk"])
+    model.load_state_dict(sd, strict=True)
+    optimizer = torch.optim.AdamW(model.parameters())                        # train.py:41
+    for group in optimizer.param_groups:                                     # train.py:43-45
+        group["lr"] = GC.TRAIN_LR
+        group["weight_decay"] = GC.TRAIN_WD
+    loss_func = RL.RSSLoss(256, 2048, 4, device="cpu")                      # train.py:48, configs/combsub.yaml
+    data = synthetic.make_inputs(GC.TRAIN_INPUT_SEED, GC.TRAIN_B, GC.TRAIN_FR)
+    data["audio"] = GC.train_target()
+    model.train()
+    names = [n for n, _ in model.named_parameters()]
+    g = {"param_names": np.array(names), "losses": [], "scales": []}
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    for step in range(GC.TRAIN_STEPS):
+        torch.manual_seed(GC.TRAIN_DRAW_SEED + step)
+        g["scales"].append(torch.randint(256, 2048, (4,)).numpy())
+        torch.manual_seed(GC.TRAIN_DRAW_SEED + step)
+        with _InjectNoise(data["noise"]):
+            optimizer.zero_grad()                                            # solver.py:110-114 from here
+            signal, _, _ = model(data["units"].float(), data["f0"], data["volume"], data["spk_id"], infer=False)
+            loss = loss_func(signal, data["audio"])
+            loss.backward()
+            optimizer.step()
+        g["losses"].append(float(loss))
+        if step == 0:
+            g["signal0_rms"] = signal.detach().pow(2).mean().sqrt()
+            g["signal0"] = signal.detach()[:, ::61]
+            g["gradnorm0"] = np.array([float(p.grad.norm()) for _, p in model.named_parameters()])
+            g["deltanorm0"] = np.array([float((p.detach() - before[n]).norm()) for n, p in model.named_parameters()])
+    g["deltanorm_all"] = np.array([float((p.detach() - before[n]).norm()) for n, p in model.named_parameters()])
+    g["losses"] = np.array(g["losses"])
+    g["scales"] = np.array(g["scales"])
+    save("ref_train_step.npz", **g)
+
+    # ---- G10 --------------------------------------------------------------------------------------------------
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+    mod("PySimpleGUI")
+    mod("sounddevice")
+    mod("soundfile")
+    mod("librosa", to_mono=lambda y: np.mean(y, axis=0))      # librosa.to_mono of a (2, n) array: the channel mean
+    mod("enhancer", Enhancer=object)
+    _fresh_reference("gui", "main", "slicer")
+    import gui as RG
+    assert RG.__file__.startswith(REF)
+
+    class _Window(dict):
+        def __missing__(self, key):
+            return types.SimpleNamespace(update=lambda *a, **k: None)
+
+    g = {}
+    for tag, use_pv in (("plain", False), ("pv", True)):
+        ui = object.__new__(RG.GUI)
+        ui.config = RG.Config()
+        ui.config.samplerate, ui.config.block_time = GC.GUI_SR, GC.GUI_BLOCK_TIME
+        ui.config.crossfade_time, ui.config.buffer_num = GC.GUI_XFADE_TIME, GC.GUI_BUFFER_NUM
+        ui.config.use_phase_vocoder = use_pv
+        ui.device = "cpu"
+        ui.resample_kernel = {}
+        ui.window = _Window()
+        # the size arithmetic of GUI.set_values (gui.py:319-326), which needs the window's values dict
+        ui.block_frame = int(ui.config.block_time * ui.config.samplerate)
+        ui.crossfade_frame = int(ui.config.crossfade_time * ui.config.samplerate)
+        ui.sola_search_frame = int(0.01 * ui.config.samplerate)
+        ui.last_delay_frame = int(0.02 * ui.config.samplerate)
+        ui.input_frames = max(ui.block_frame + ui.crossfade_frame + ui.sola_search_frame + 2 * ui.last_delay_frame,
+                              (1 + ui.config.buffer_num) * ui.block_frame)
+        ui.f_safe_prefix_pad_length = 0
+        # GUI.start_vc (gui.py:344-351) without the model load and the thread
+        ui.input_wav = np.zeros(ui.input_frames, dtype="float32")
+        ui.sola_buffer = torch.zeros(ui.crossfade_frame)
+        ui.fade_in_window = torch.sin(np.pi * torch.arange(0, 1, 1 / ui.crossfade_frame) / 2) ** 2
+        ui.fade_out_window = 1 - ui.fade_in_window
+        state = {"k": 0}
+        ui.svc_model = types.SimpleNamespace(
+            infer=lambda audio, sr, **kw: (GC.gui_model_output(state["k"]).clone(), GC.GUI_SR))
+        shifts, outs = [], []
+        for k in range(GC.GUI_BLOCKS):
+            state["k"] = k
+            outdata = np.zeros((ui.block_frame, 2), dtype=np.float32)
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                ui.audio_callback(GC.gui_indata(k), outdata, ui.block_frame, None, None)
+            shifts.append(int(re.search(r"sola_shift: (\d+)", buf.getvalue()).group(1)))
+            outs.append(outdata.copy())
+        g[f"shift_{tag}"] = np.array(shifts)
+        outs = np.stack(outs)
+        assert np.array_equal(outs[..., 0], outs[..., 1])     # gui.py:430 duplicates the mono block to two channels
+        if tag == "plain":
+            g["out_plain"] = outs[..., 0]
+        else:       # beyond the cross-faded head the two variants emit the same samples (same shifts): store the heads
+            assert np.array_equal(outs[:, ui.crossfade_frame:, 0], g["out_plain"][:, ui.crossfade_frame:])
+            g["head_pv"] = outs[:, :ui.crossfade_frame, 0]
+        g[f"buffer_{tag}"] = ui.sola_buffer.clone()
+        g[f"input_wav_{tag}"] = ui.input_wav[-3 * ui.block_frame::37].copy()
+    g["sizes"] = np.array([ui.block_frame, ui.crossfade_frame, ui.sola_search_frame, ui.last_delay_frame, ui.input_frames])
+    save("ref_gui_stream.npz", **g)
+
+    # volume gate as SvcDDSP.infer computes and applies it; the extractors and the model are stand-ins
+    svc = object.__new__(RG.SvcDDSP)
+    svc.device = "cpu"
+    svc.args = types.SimpleNamespace(data=types.SimpleNamespace(block_size=HOP, sampling_rate=SR))
+    n_fr = GC.GATE_T // HOP + 1
+
+    class _F0:
+        def __init__(self, *a):
+            pass
+
+        def extract(self, audio, **kw):
+            return np.full(n_fr, 220.0)
+
+    RG.F0_Extractor = _F0
+    svc.units_encoder = types.SimpleNamespace(encode=lambda a, sr, hop: torch.zeros(1, n_fr, 256))
+    seen = {}
+
+    def _model(units, f0, volume, spk_id=None, spk_mix_dict=None):
+        seen["volume"] = np.asarray(volume).copy()
+        return GC.gate_model_output().clone(), None, (None, None)
+
+    svc.model = _model
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        out, sr_out = svc.infer(GC.gate_audio(), SR, spk_id=1, threhold=GC.GATE_THRESHOLD, use_enhancer=False)
+    assert sr_out == SR
+    og = {"gated": out, "volume": seen["volume"]}
+    import main as RM
+    assert RM.__file__.startswith(REF)
+    for i, (a, b, idx) in enumerate(GC.crossfade_cases()):
+        og[f"xfade_{i}"] = RM.cross_fade(a, b, idx)
+    save("ref_offline_glue.npz", **og)
+    sys.path.remove(REF)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["a", "b", "c", "d"]
+    which = sys.argv[1:] or ["a", "b", "c", "d", "e"]
     torch.set_num_threads(4)
     if "a" in which:
         tier_a()
@@ -376,3 +613,5 @@ if __name__ == "__main__":
         tier_b()
     if "d" in which:
         tier_d()
+    if "e" in which:
+        tier_e()

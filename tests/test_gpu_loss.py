@@ -75,3 +75,34 @@ def test_rss_module_api(dev, lib_path):
     assert abs(float(s) - float(OL.sss_loss(xt, xp.detach().cpu(), 300))) < 2e-5
     with pytest.raises(ValueError):
         RSSLoss(256, 2048, 4, overlap=0.5)(xp, xt.to(dev))
+
+
+def test_rss_against_reference_run(ctx, dev):
+    """G8: the HIP loss against outputs of the reference's own `ddsp/loss.py` (tests/golden/ref_loss.npz, made by
+    make_golden.py tier e; only torchaudio's Spectrogram was a stand-in there)."""
+    import os
+    import glue_cases as GC
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "ref_loss.npz"))
+    xp, xt = GC.loss_signals()
+    for N in GC.LOSS_SCALES:
+        loss, grad = ctx.rss_loss(xp.to(dev), xt.to(dev), [N], want_grad=True)
+        assert abs(float(loss) - float(z[f"sss_{N}"])) < 2e-5 * float(z[f"sss_{N}"]), N
+        g64 = torch.from_numpy(z[f"sss64_grad_{N}"])
+        ref_err = float((torch.from_numpy(z[f"sss_grad_{N}"]).double() - g64).norm() / g64.norm())
+        err = float((grad.cpu()[:, ::97].double() - g64).norm() / g64.norm())
+        # the reference's fp32 gradient is itself this far (ref_err) from its fp64 evaluation
+        assert err < max(3 * ref_err, 2e-3), (N, err, ref_err)
+        assert abs(float(grad.norm()) - float(z[f"sss64_gradnorm_{N}"])) < max(3 * ref_err, 2e-3) * float(z[f"sss64_gradnorm_{N}"])
+    # RSSLoss.forward under the same torch seed: same draw, same value, same gradient
+    from ddsp.loss import RSSLoss
+    crit = RSSLoss(256, 2048, 4, device=dev)
+    x = xp.to(dev).requires_grad_(True)
+    torch.manual_seed(GC.RSS_SEED)
+    v = crit(x, xt.to(dev))
+    v.backward()
+    assert crit.last_scales == [int(s) for s in z["rss_scales"]]
+    assert abs(float(v.detach()) - float(z["rss"])) < 2e-5 * float(z["rss"])
+    gw = torch.from_numpy(z["rss_grad"])
+    assert float((x.grad.cpu()[:, ::97] - gw).norm() / gw.norm()) < 5e-3
+    assert abs(float(x.grad.norm()) - float(z["rss_gradnorm"])) < 5e-3 * float(z["rss_gradnorm"])

@@ -182,3 +182,38 @@ def test_splicer_with_phase_vocoder(dev, lib_path):
         start = n - pv.block - pv.xfade - pv.search - pv.delay + int(pv.last_shift)
         want = realtime.phase_vocoder(kept, x[start:start + pv.xfade], pv.fade_out, pv.fade_in)
         assert torch.equal(e_pv[:pv.xfade], want)
+
+
+@pytest.mark.parametrize("use_pv", [False, True])
+def test_splicer_against_reference_callback(dev, lib_path, use_pv):
+    """G10: `realtime.Splicer` over eight blocks against the reference's own `gui.GUI.audio_callback`
+    (tests/golden/ref_gui_stream.npz: make_golden.py tier e ran the callback on an object made without its window)."""
+    import glue_cases as GC
+    import realtime
+    z = np.load(os.path.join(GOLDEN, "ref_gui_stream.npz"))
+    block, xfade, search, delay, n_in = [int(v) for v in z["sizes"]]
+    sp = realtime.Splicer(GC.GUI_SR, GC.GUI_BLOCK_TIME, GC.GUI_XFADE_TIME, dev, use_phase_vocoder=use_pv)
+    assert (sp.block, sp.xfade, sp.search, sp.delay) == (block, xfade, search, delay)
+    assert sp.input_frames(GC.GUI_BUFFER_NUM) == n_in
+    tag = "pv" if use_pv else "plain"
+    for k in range(GC.GUI_BLOCKS):
+        emitted = sp.push(GC.gui_model_output(k).to(dev))
+        assert int(sp.last_shift.item()) == int(z[f"shift_{tag}"][k]), k
+        e = emitted.cpu()
+        assert (e[xfade:] - torch.from_numpy(z["out_plain"][k][xfade:])).abs().max() == 0, k
+        if use_pv:
+            assert (e[:xfade] - torch.from_numpy(z["head_pv"][k])).abs().max() < 2e-5, k
+        else:
+            assert (e - torch.from_numpy(z["out_plain"][k])).abs().max() < 2e-6, k
+    assert (sp.buffer.cpu() - torch.from_numpy(z[f"buffer_{tag}"])).abs().max() < 1e-6
+
+
+def test_gate_against_reference_infer(ctx, dev):
+    """The volume gate as `gui.SvcDDSP.infer` computes and applies it (gui.py:103-112,125-127; executed by the fixture
+    generator with stand-ins for the extractors and the model): device volume extraction + device gate."""
+    import glue_cases as GC
+    z = np.load(os.path.join(GOLDEN, "ref_offline_glue.npz"))
+    vol = ctx.volume_extract(torch.from_numpy(GC.gate_audio())[None].to(dev), HOP)
+    assert np.allclose(vol.cpu().numpy()[0], z["volume"], rtol=2e-6, atol=0)
+    out = ctx.volume_gate_(GC.gate_model_output().to(dev).clone(), vol, GC.GATE_THRESHOLD, HOP)
+    assert torch.equal(out.cpu()[0], torch.from_numpy(z["gated"]))

@@ -163,3 +163,44 @@ def test_loss_decreases_over_steps(dev, lib_path):
     crit = RSSLoss(256, 2048, 4, device=dev)
     losses = [float(training.train_step(model, opt, crit, inp, scales=[256, 512, 1024, 2000])) for _ in range(12)]
     assert all(np.isfinite(losses)) and min(losses[1:]) < 0.98 * losses[0] and losses[-1] < losses[0], losses
+
+
+def test_train_steps_against_reference_run(dev, lib_path):
+    """G9: `training.train_step` x3 against three iterations of the reference's own loop (solver.py:110-114 on the
+    reference CombSub with torch.optim.AdamW and the reference RSSLoss; tests/golden/ref_train_step.npz).  Iteration 0
+    is the tight check; why the later ones can only be loose is written in tests/test_oracle_golden.py."""
+    import os
+    import glue_cases as GC
+    import training
+    from conftest import GOLDEN
+    from ddsp.loss import RSSLoss
+    z = np.load(os.path.join(GOLDEN, "ref_train_step.npz"))
+    model, cfg = synthetic.build_model("CombSub", seed=GC.TRAIN_WEIGHT_SEED)
+    names = [n for n, _ in model.named_parameters()]
+    assert names == [str(n) for n in z["param_names"]]
+    model = model.to(dev).train()
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    opt = training.AdamW(model.parameters())                                 # train.py:41, then :43-45
+    for group in opt.param_groups:
+        group["lr"], group["weight_decay"] = GC.TRAIN_LR, GC.TRAIN_WD
+    crit = RSSLoss(256, 2048, 4, device=dev)
+    batch = {k: v.to(dev) for k, v in synthetic.make_inputs(GC.TRAIN_INPUT_SEED, GC.TRAIN_B, GC.TRAIN_FR).items()}
+    batch["audio"] = GC.train_target().to(dev)
+    losses = []
+    for step in range(GC.TRAIN_STEPS):
+        torch.manual_seed(GC.TRAIN_DRAW_SEED + step)                         # the reference's draw, not a pinned list
+        losses.append(float(training.train_step(model, opt, crit, batch)))
+        assert crit.last_scales == [int(v) for v in z["scales"][step]]
+        if step == 0:
+            gn = np.array([float(p.grad.norm()) for _, p in model.named_parameters()])
+            d0 = np.array([float((p.detach() - before[n]).norm()) for n, p in model.named_parameters()])
+    want = z["losses"]
+    assert abs(losses[0] - want[0]) < 2e-4 * want[0], (losses, want)
+    assert abs(losses[1] - want[1]) < 2e-3 * want[1], (losses, want)
+    assert abs(losses[2] - want[2]) < 3e-2 * want[2], (losses, want)
+    assert losses[2] < losses[1] < losses[0]
+    # train mode integrates the phase with per-sample fp32 rounding: single-ulp flips move gradients by ~1e-2
+    assert np.allclose(gn, z["gradnorm0"], rtol=5e-2, atol=1e-6), np.abs(gn / z["gradnorm0"] - 1).max()
+    assert np.allclose(d0, z["deltanorm0"], rtol=2e-2, atol=1e-7), np.abs(d0 / z["deltanorm0"] - 1).max()
+    dall = np.array([float((p.detach() - before[n]).norm()) for n, p in model.named_parameters()])
+    assert np.allclose(dall, z["deltanorm_all"], rtol=0.5, atol=1e-7)
