@@ -30,16 +30,22 @@ SR = 44100
 BYTES_PER_SAMPLE_API = 6.02   # units 256*4 + f0 4 + volume 4 in, 512*4 + 4 out per frame
 PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_MFMA_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
-# The two kernel families with the largest shares of the step (profiles/); both are bracketed by HIP events in the timed
-# region and the one that took longer is reported as `roofline`, the other as `roofline_other`.
+# The kernel families with the largest shares of the step (profiles/); all are bracketed by HIP events in the timed
+# region; the one that took longest is reported as `roofline`, the others under `roofline_others`.
 #  * ltv_fir: frame-varying FIR as Toeplitz-block products (v_mfma_f32_16x16x32_bf16, operands split into bf16 hi/lo
 #    planes while they are staged into the LDS).
 #  * u2c_gemm_linear: the control network's Linear layers, the SPLIT-bf16 mode of the DMA GEMM at the bench batch.
-#  In both every fp32 product is formed from 3 bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulation), so the kernel ISSUES
-#  three times its algorithmic FLOP on the bf16 pipe.  The roofline entries therefore hold issued bf16 FLOP/s against the
-#  bf16 dense peak (the same fraction as algorithmic FLOP/s against peak/3) and carry the algorithmic rate alongside.
-FAMILIES_TIMED = ("ltv_fir", "u2c_gemm_linear")
+#  * u2c_gemm_ctx / u2c_gemm_attnout: the fused Performer attention kernels (key side / query side).
+#  `frac` = ALGORITHMIC FLOP / time / dense peak of the matrix pipe the kernel issues on (bf16 2.5 PFLOP/s for the split
+#  kernels, fp32 157.3 TFLOP/s otherwise).  A split-bf16 kernel forms every fp32 product from 3 bf16 MFMAs (hi*hi + hi*lo +
+#  lo*hi, fp32 accumulation), i.e. ISSUES three times its algorithmic FLOP: that utilisation figure is `mfma_issue_frac`.
+FAMILIES_TIMED = ("ltv_fir", "u2c_gemm_linear", "u2c_gemm_ctx", "u2c_gemm_attnout")
+SPLIT_FAMILIES = ("ltv_fir", "u2c_gemm_linear")     # families whose products follow the context's math mode
 KERNEL_LABEL = {
+    "u2c_gemm_ctx": "performer_kv_kernel (fused key feature map + k'^T v context, fp32 MFMA 16x16x4, one wavefront per "
+                    "(utterance, head, feature tile); three launches per step)",
+    "u2c_gemm_attnout": "performer_q_kernel (fused query feature map + q' ctx / (q' ks), fp32 MFMA 16x16x4, one wavefront "
+                        "per (utterance, head, frame tile); three launches per step)",
     "ltv_fir": "ltv_fir_bf16_kernel (frame-varying FIR as Toeplitz-block products, split-bf16 = 3 bf16 MFMA 16x16x32 per "
                "fp32 product, operands split while staged into the LDS; three launches per step: all-pass 510 taps, "
                "source 1022 taps, noise 510 taps)",
@@ -89,8 +95,20 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(seed):
-    """Times the oracle's CombSub forward on the host cores: B=8 clips of 2 s, median of 3 (about 10-30 s)."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(seed, inp_cpu):
+    """Times the oracle's CombSub forward (a port of the reference's PyTorch CPU path) on the host cores, on the SAME 64
+    clips the GPU renders (same inputs, same B): median of 5 on the job's core share, plus a one-thread figure
+    on the first 8 of those clips (median of 3) - about 15-25 s in total."""
     import synthetic
     from oracle import synth as OS
     # the GPU box gives one GPU's job a 16-core share; more threads than that only oversubscribes ATen's pools
@@ -98,21 +116,58 @@ def cpu_baseline(seed):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(16, avail)))
-    Bc = 8
-    model, cfg = synthetic.build_model("CombSub", seed=seed)
+    threads = max(1, min(16, avail))
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):       # (the constructor prints the reference's banner line)
+        model, cfg = synthetic.build_model("CombSub", seed=seed)
     sd = model.state_dict()
-    inp = synthetic.make_inputs(seed + 1, Bc, FRAMES)
-    times = []
+    g = torch.Generator().manual_seed(seed)
+    noise = torch.rand(B_PER_GPU, FRAMES * HOP, generator=g)
+
+    def run(nb, reps):
+        a = {k: v[:nb] for k, v in inp_cpu.items()}
+        times = []
+        with torch.no_grad():
+            OS.combsub_forward(sd, cfg, a["units"], a["f0"], a["volume"], a["spk_id"], noise=noise[:nb])
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                OS.combsub_forward(sd, cfg, a["units"], a["f0"], a["volume"], a["spk_id"], noise=noise[:nb])
+                times.append(time.perf_counter() - t0)
+        return sorted(times)[reps // 2]
+
+    torch.set_num_threads(threads)
+    t_all = run(B_PER_GPU, 5)
+    torch.set_num_threads(1)
+    t_one = run(8, 3)
+    torch.set_num_threads(threads)
+    return {"value": B_PER_GPU * FRAMES * HOP / t_all, "unit": "samples/s", "cores": threads, "kind": "port",
+            "cpu_model": _cpu_model(), "value_1_thread": 8 * FRAMES * HOP / t_one,
+            "sample": f"oracle CombSub.forward on the bench inputs: B={B_PER_GPU} x 2 s clips, median of 5 on {threads} ATen "
+                      f"threads ({t_all * 1e3:.0f} ms each); 1 thread: the first 8 clips, median of 3 ({t_one * 1e3:.0f} ms each)"}
+
+
+def parity_sample(model_cpu_sd, cfg, model, inp, inp_cpu, seed, ctx, dev):
+    """RMS error of the BENCHED arithmetic against the CPU oracle: the whole 64-clip batch is rendered once more with an
+    injected noise draw (same kernels and batch-dependent kernel choices as the timed steps), 8 of the 64 clips are
+    compared with the oracle's rendering of the same clips.  Once per product-arithmetic mode."""
+    from oracle import synth as OS
+    import hipddsp
+    g = torch.Generator().manual_seed(seed + 5)
+    noise = torch.rand(B_PER_GPU, FRAMES * HOP, generator=g)
+    pick = list(range(0, B_PER_GPU, B_PER_GPU // 8))
+    a = {k: v[pick] for k, v in inp_cpu.items()}
     with torch.no_grad():
-        OS.combsub_forward(sd, cfg, inp["units"], inp["f0"], inp["volume"], inp["spk_id"], noise=inp["noise"])
-        for _ in range(3):
-            t0 = time.perf_counter()
-            OS.combsub_forward(sd, cfg, inp["units"], inp["f0"], inp["volume"], inp["spk_id"], noise=inp["noise"])
-            times.append(time.perf_counter() - t0)
-    t = sorted(times)[1]
-    return {"value": Bc * FRAMES * HOP / t, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle CombSub.forward, B={Bc} x 2 s clips, median of 3 ({t * 1e3:.0f} ms each)"}
+        want = OS.combsub_forward(model_cpu_sd, cfg, a["units"], a["f0"], a["volume"], a["spk_id"], noise=noise[pick])[0]
+    out = {"clips_compared": len(pick), "signal_rms": float(want.double().pow(2).mean().sqrt()), "gate": 1e-4}
+    keep = ctx.math
+    nd = noise.to(dev)
+    for name, mode in (("split_bf16x3", hipddsp.MATH_SPLIT_BF16), ("fp32_mfma", hipddsp.MATH_FP32)):
+        ctx.set_math(mode)
+        with torch.no_grad():
+            sig = model(inp["units"], inp["f0"], inp["volume"], inp["spk_id"], noise=nd)[0]
+        out["rms_error_" + name] = float((sig[pick].cpu().double() - want.double()).pow(2).mean().sqrt())
+    ctx.set_math(keep)
+    return out
 
 
 def main():
@@ -148,8 +203,8 @@ def main():
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):      # the constructors print the reference's banner line; stdout is for the JSON
         model, cfg = synthetic.build_model(args.model, seed=seed, device=dev)
-    inp = synthetic.make_inputs(seed + 100 + rank, B_PER_GPU, FRAMES, with_noise=False)
-    inp = {k: v.to(dev) for k, v in inp.items()}
+    inp_cpu = synthetic.make_inputs(seed + 100 + rank, B_PER_GPU, FRAMES, with_noise=False)
+    inp = {k: v.to(dev) for k, v in inp_cpu.items()}
     T = FRAMES * HOP
     ctx = hipddsp.context_for(dev)
 
@@ -180,32 +235,46 @@ def main():
                 gather.submit(sig)
             return sig
 
-    for i in range(args.warmup):
-        step(i)
-    if gather is not None:
-        gather.wait()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # HIP events around the two largest families only (16 brackets = 32 records per step; created without the system-scope
-    # fence: with default events the brackets cost 0.095 ms per step, now 0.035 ms - measured against a run without them)
-    ctx.profile_begin(list(FAMILIES_TIMED))
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    if gather is not None:
-        gather.wait()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    timed = ctx.profile_end()
-    if dist is not None:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def timed_leg(base):
+        """W warm-up steps, then exactly K steps between barrier + synchronize pairs; max over ranks."""
+        for i in range(args.warmup):
+            step(base + i)
+        if gather is not None:
+            gather.wait()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        # HIP events around the largest families only (22 brackets = 44 records per step; created without the system-scope
+        # fence: with default events 16 brackets cost 0.095 ms per step, without it 0.035 ms - measured against a run
+        # without them)
+        ctx.profile_begin(list(FAMILIES_TIMED))
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(base + args.warmup + i)
+        if gather is not None:
+            gather.wait()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        timed = ctx.profile_end()
+        if dist is not None:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, timed
+
+    # leg 1 (`value`): the library's default product arithmetic (split-bf16x3 at this batch)
+    dt, timed = timed_leg(0)
+    # leg 2 (`value_fp32_mfma`): the same steps with every contraction on the fp32 matrix pipe (the reference's precision
+    # class); the training step's backward is fp32 in both, so the second leg is a synth-mode figure
+    dt32 = timed32 = None
+    if args.mode == "synth":
+        ctx.set_math(hipddsp.MATH_FP32)
+        dt32, timed32 = timed_leg(100_000)
+        ctx.set_math(hipddsp.MATH_SPLIT_BF16)
 
     total_samples = world * Bt * T * args.steps
     value = total_samples / dt
@@ -215,7 +284,10 @@ def main():
                   f"audio samples/sec @44.1kHz {args.model} training step (fwd + RSS loss + bwd + AdamW)",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": ("f32 storage and accumulation; products of the GEMM/FIR contractions split-bf16x3 (hi*hi+hi*lo+lo*hi), "
+                  "attention and all other arithmetic f32; `value_fp32_mfma` is the all-f32 leg") if args.mode == "synth"
+        else "f32 (forward GEMM/FIR products split-bf16x3; backward, loss and optimizer f32)",
+        "data": "synthetic",
         "config": {"workload": f"{args.model} 44.1 kHz, batch={Bt}x2 s per GPU (Fr={FRAMES}, T={T}), "
                                + ("units/f0/volume/spk_id -> audio, seeded random weights, in-kernel noise"
                                   if args.mode == "synth" else
@@ -225,6 +297,9 @@ def main():
         "x_realtime": value / SR,
         "hbm_frac_api_bytes": value * BYTES_PER_SAMPLE_API / 8e12,
     }
+    if dt32 is not None:
+        out["value_fp32_mfma"] = total_samples / dt32
+        out["ms_per_step_fp32_mfma"] = dt32 / args.steps * 1e3
     # untimed breakdown pass: every kernel family bracketed by events (adds launch gaps, so not part of `value`)
     ctx.profile_begin()
     nb = 3
@@ -235,7 +310,7 @@ def main():
     torch.cuda.synchronize()
     fam = ctx.profile_end()
     if rank == 0:
-        def roofline_of(name):
+        def roofline_of(name, timed, split):
             d = timed[name]
             avg_ms = d["ms_total"] / d["launches"]
             alg = d["flops_total"] / d["launches"] / (avg_ms * 1e-3) / 1e12
@@ -244,17 +319,21 @@ def main():
                  "ms_per_step": d["ms_total"] / args.steps,
                  "algorithmic_bytes_per_launch": d["bytes_total"] / d["launches"],
                  "algorithmic_flops_per_launch": d["flops_total"] / d["launches"]}
-            if name == "ltv_fir" or args.mode == "synth":
+            if split and (name == "ltv_fir" or (name in SPLIT_FAMILIES and args.mode == "synth")):
                 r.update({"arithmetic": "split-bf16: 3 bf16 MFMAs per fp32 product, fp32 accumulation",
-                          "achieved": 3.0 * alg, "peak": PEAK_MFMA_BF16_TFLOPS, "frac": 3.0 * alg / PEAK_MFMA_BF16_TFLOPS,
-                          "algorithmic_tflops": alg})
+                          "achieved": alg, "peak": PEAK_MFMA_BF16_TFLOPS, "frac": alg / PEAK_MFMA_BF16_TFLOPS,
+                          "mfma_issue_frac": 3.0 * alg / PEAK_MFMA_BF16_TFLOPS})
             else:
                 r.update({"arithmetic": "fp32 MFMA", "achieved": alg, "peak": PEAK_MFMA_F32_TFLOPS,
                           "frac": alg / PEAK_MFMA_F32_TFLOPS})
             return r
-        order = sorted(FAMILIES_TIMED, key=lambda f: -timed[f]["ms_total"])
-        out["roofline"] = roofline_of(order[0])
-        out["roofline_other"] = roofline_of(order[1])
+        present = [f for f in FAMILIES_TIMED if f in timed]
+        order = sorted(present, key=lambda f: -timed[f]["ms_total"])
+        out["roofline"] = roofline_of(order[0], timed, True)
+        out["roofline_others"] = [roofline_of(f, timed, True) for f in order[1:]]
+        if timed32 is not None:
+            out["roofline_fp32_mfma_leg"] = [roofline_of(f, timed32, False)
+                                             for f in sorted(present, key=lambda f: -timed32[f]["ms_total"])]
         out["kernel_families_ms_per_step"] = {k: round(v["ms_total"] / nb, 4) for k, v in fam.items()}
         out["kernel_families_tflops"] = {k: round(v["flops_total"] / (v["ms_total"] * 1e-3) / 1e12, 2)
                                          for k, v in fam.items() if v["flops_total"] > 0}
@@ -262,8 +341,10 @@ def main():
         # against the 8 TB/s HBM roofline for the families that are HBM-bound (scan, activations, row kernels, prep)
         out["kernel_families_gbps_algorithmic"] = {k: round(v["bytes_total"] / (v["ms_total"] * 1e-3) / 1e9, 1)
                                                    for k, v in fam.items() if v["bytes_total"] > 0 and v["ms_total"] > 0}
-        if world == 1 and not args.no_cpu_baseline and args.mode == "synth":
-            out["cpu_baseline"] = cpu_baseline(seed)
+        if world == 1 and not args.no_cpu_baseline and args.mode == "synth" and args.model == "CombSub":
+            cpu_sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+            out["parity_vs_oracle"] = parity_sample(cpu_sd, cfg, model, inp, inp_cpu, seed, ctx, dev)
+            out["cpu_baseline"] = cpu_baseline(seed, inp_cpu)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -34,6 +34,7 @@ struct ddsp_prof_rec {
 
 struct ddsp_ctx {
     int device;
+    int math;   // product arithmetic of the inference GEMMs (ddsp_ctx_set_math): DDSP_MATH_SPLIT_BF16 (default) or DDSP_MATH_FP32
     // profiler
     uint64_t prof_mask;
     ddsp_prof_rec* prof;
@@ -51,6 +52,10 @@ struct ddsp_ctx {
     size_t packed_bytes;
     // 8 KiB of zeros: the source of out-of-range conv taps in the LDS-DMA GEMM (a DMA cannot be predicated to zero)
     float* zero_page;
+    // device-side contract violations (a speaker id outside the table): one int in host-mapped memory that kernels set
+    // with a system-scope store; the next entry point that takes ids, or ddsp_ctx_poll_error, reports and clears it
+    int* dev_error_host;
+    int* dev_error_dev;
 };
 
 static inline int ddsp_fail(ddsp_ctx* ctx, int code, const char* what, const char* detail) {
@@ -84,6 +89,11 @@ int ddsp_get_table(ddsp_ctx* ctx, hipStream_t st, int kind, int n0, int n1, floa
 // device pointer to DDSP_ZERO_FLOATS zeros (allocated on first use; a first-use synchronisation like the tables)
 constexpr int DDSP_ZERO_FLOATS = 2048;
 int ddsp_zero_page(ddsp_ctx* ctx, const float** out);
+// device pointer to the context's error flag (allocated on first use); ddsp_take_dev_error returns DDSP_ERR_ARG and
+// clears the flag when a kernel of an earlier, completed call raised it
+int ddsp_dev_error_ptr(ddsp_ctx* ctx, int** out);
+int ddsp_take_dev_error(ddsp_ctx* ctx);
+#define DDSP_DEV_ERR_SPK_ID 1
 
 // profiler hooks (ctx.hip): bracket ONE kernel launch (or a tight group) on `st` when the family is enabled
 void ddsp_prof_begin(ddsp_ctx* ctx, hipStream_t st, int id);

@@ -12,6 +12,7 @@ extern "C" int ddsp_ctx_create(ddsp_ctx** out, int device) {
     ddsp_ctx* c = (ddsp_ctx*)calloc(1, sizeof(ddsp_ctx));
     if (!c) return DDSP_ERR_OOM;
     c->device = device;
+    c->math = DDSP_MATH_SPLIT_BF16;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) {
@@ -33,6 +34,7 @@ extern "C" int ddsp_ctx_destroy(ddsp_ctx* ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->packed) (void)hipFree(ctx->packed);
     if (ctx->zero_page) (void)hipFree(ctx->zero_page);
+    if (ctx->dev_error_host) (void)hipHostFree(ctx->dev_error_host);
     if (ctx->prof) {
         for (int i = 0; i < ctx->prof_events_made; ++i) {
             (void)hipEventDestroy(ctx->prof[i].start);
@@ -45,6 +47,15 @@ extern "C" int ddsp_ctx_destroy(ddsp_ctx* ctx) {
     free(ctx);
     return DDSP_OK;
 }
+
+extern "C" int ddsp_ctx_set_math(ddsp_ctx* ctx, int math) {
+    if (!ctx) return DDSP_ERR_ARG;
+    DDSP_REQUIRE(ctx, math == DDSP_MATH_FP32 || math == DDSP_MATH_SPLIT_BF16, "ddsp_ctx_set_math: unknown mode");
+    ctx->math = math;
+    return DDSP_OK;
+}
+
+extern "C" int ddsp_ctx_get_math(const ddsp_ctx* ctx) { return ctx ? ctx->math : DDSP_ERR_ARG; }
 
 extern "C" const char* ddsp_last_error(const ddsp_ctx* ctx) { return ctx ? ctx->err : "null ctx"; }
 
@@ -152,6 +163,41 @@ extern "C" int ddsp_profile_end(ddsp_ctx* ctx, ddsp_prof_entry* out, int max_ent
     *n_entries = n;
     ctx->prof_n = 0;
     return DDSP_OK;
+}
+
+int ddsp_dev_error_ptr(ddsp_ctx* ctx, int** out) {
+    if (!ctx->dev_error_host) {
+        DDSP_HIP(ctx, hipSetDevice(ctx->device));
+        int* h = nullptr;
+        hipError_t e = hipHostMalloc((void**)&h, 64, hipHostMallocMapped);
+        if (e != hipSuccess) return ddsp_fail(ctx, DDSP_ERR_OOM, "error flag hipHostMalloc", hipGetErrorString(e));
+        *h = 0;
+        int* d = nullptr;
+        e = hipHostGetDevicePointer((void**)&d, h, 0);
+        if (e != hipSuccess) {
+            (void)hipHostFree(h);
+            return ddsp_fail(ctx, DDSP_ERR_HIP, "hipHostGetDevicePointer", hipGetErrorString(e));
+        }
+        ctx->dev_error_host = h;
+        ctx->dev_error_dev = d;
+    }
+    *out = ctx->dev_error_dev;
+    return DDSP_OK;
+}
+
+int ddsp_take_dev_error(ddsp_ctx* ctx) {
+    if (!ctx->dev_error_host) return DDSP_OK;
+    const int code = __atomic_exchange_n(ctx->dev_error_host, 0, __ATOMIC_ACQ_REL);
+    if (code == DDSP_DEV_ERR_SPK_ID)
+        return ddsp_fail(ctx, DDSP_ERR_ARG, "spk_id out of range [1, n_spk] in an earlier ddsp_unit2ctrl call",
+                         "the speaker embedding of those rows was skipped (the reference's nn.Embedding raises)");
+    if (code) return ddsp_fail(ctx, DDSP_ERR_ARG, "device-side contract violation in an earlier call", "");
+    return DDSP_OK;
+}
+
+extern "C" int ddsp_ctx_poll_error(ddsp_ctx* ctx) {
+    if (!ctx) return DDSP_ERR_ARG;
+    return ddsp_take_dev_error(ctx);
 }
 
 int ddsp_zero_page(ddsp_ctx* ctx, const float** out) {

@@ -220,7 +220,8 @@ struct MixArgs {
 __global__ void __launch_bounds__(256) embed_add_kernel(float* __restrict__ x, const float* __restrict__ f0,
                                                         const float* __restrict__ phase, const float* __restrict__ vol,
                                                         const ddsp_u2c_weights w, const int64_t* __restrict__ spk_id,
-                                                        int64_t n_spk_id, MixArgs mix, int64_t rows, int Fr) {
+                                                        int64_t n_spk_id, MixArgs mix, int64_t rows, int Fr,
+                                                        int* __restrict__ err) {
     // one wave per row, 4 channels per lane (the per-row log / divisions used to be redone for every element)
     const int lane = threadIdx.x & 63, c = lane * 4;
     const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -247,9 +248,14 @@ __global__ void __launch_bounds__(256) embed_add_kernel(float* __restrict__ x, c
         }
     } else {
         const int64_t id = spk_id[n_spk_id == 1 ? 0 : m / Fr];
-        const v4 e = *(const v4*)(w.spk_table + (id - 1) * D + c);
+        if (id >= 1 && id <= w.n_spk) {
+            const v4 e = *(const v4*)(w.spk_table + (id - 1) * D + c);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += e[j];
+            for (int j = 0; j < 4; ++j) v[j] += e[j];
+        } else if (lane == 0) {
+            // outside the table (the reference's nn.Embedding raises): nothing is read, the host is told
+            __hip_atomic_store(err, DDSP_DEV_ERR_SPK_ID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     *(f32x4*)(x + m * D + c) = v;
 }
@@ -379,8 +385,6 @@ __global__ void __launch_bounds__(256) glu_kernel(const float* __restrict__ g1, 
 // preparation launch) so that the 31 tap loads are contiguous rows too - in the (512, 31) parameter layout every
 // tap load of a wavefront touches 64 cache lines, which cost more than the convolution itself.
 constexpr int DW_RUN = 32;
-// 3 = split-bf16 products (3 bf16 MFMAs per fp32 product) for the inference GEMMs of the control network; 0 = fp32 MFMA
-constexpr int U2C_INFER_MATH = 3;
 // SILU: apply SiLU (forward) and optionally keep the pre-activation; FLIP: correlate with reversed taps and no
 // bias (the input-gradient of the same convolution).
 template <bool SILU, bool FLIP>
@@ -802,7 +806,7 @@ __global__ void __launch_bounds__(256) weight_norm_bwd_kernel(const float* __res
 // speaker's row (atomics: several utterances may share a speaker), or w_k * (sum over everything) in mix mode
 __global__ void __launch_bounds__(256) spk_embed_bwd_kernel(const float* __restrict__ dx, int64_t B, int Fr,
                                                             const int64_t* __restrict__ spk_id, int64_t n_spk_id,
-                                                            MixArgs mix, float* __restrict__ dtable) {
+                                                            MixArgs mix, float* __restrict__ dtable, int n_spk) {
     const int c = threadIdx.x;  // D == 256 channels
     const int64_t b = blockIdx.x;
     float s = 0.f;
@@ -811,7 +815,7 @@ __global__ void __launch_bounds__(256) spk_embed_bwd_kernel(const float* __restr
         for (int k = 0; k < mix.n; ++k) atomicAdd(dtable + (mix.ids[k] - 1) * D + c, mix.w[k] * s);
     } else {
         const int64_t id = spk_id[n_spk_id == 1 ? 0 : b];
-        atomicAdd(dtable + (id - 1) * D + c, s);
+        if (id >= 1 && id <= n_spk) atomicAdd(dtable + (id - 1) * D + c, s);   // (the forward has raised the error flag)
     }
 }
 
@@ -927,9 +931,11 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
     const size_t n_w1 = (size_t)D * 3 * w.n_unit, n_w2 = (size_t)D * 3 * D, n_wh = (size_t)w.n_out * D;
     // product arithmetic of the Linear / conv GEMMs (gemm::Args::math): inference uses the split-bf16 mode, the
     // training forward (activations kept for the backward pass) stays on fp32 MFMA like the backward GEMMs
-    const int lin_math = bf.l[0].pre ? 0 : U2C_INFER_MATH;
+    const int lin_math = bf.l[0].pre ? 0 : ctx->math;
     const float* zero_page = nullptr;   // source of the conv taps that fall off an utterance (LDS-DMA conv GEMM)
     if (int rc = ddsp_zero_page(ctx, &zero_page)) return rc;
+    int* dev_err = nullptr;
+    if (int rc = ddsp_dev_error_ptr(ctx, &dev_err)) return rc;
     // Inference, and enough rows that the Linear layers run the 128x128 DMA tile anyway: GLU is formed inside the pw1
     // GEMM (half the store, no glu kernel).  Training keeps pw1's raw output for the backward pass; small batches keep
     // the tile shapes that suit them and the separate glu kernel.
@@ -986,7 +992,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
     }
     PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
          hipLaunchKernelGGL(embed_add_kernel, dim3((unsigned)ceil_div64(M, 4)), dim3(256), 0, st, x, in.f0, in.phase, in.volume, w,
-                            in.spk_id, in.n_spk_id, in.mix, M, (int)Fr));
+                            in.spk_id, in.n_spk_id, in.mix, M, (int)Fr, dev_err));
     DDSP_LAUNCH_CHECK(ctx);
 
     const unsigned rows_g = (unsigned)ceil_div64(M, 4), rows8_g = (unsigned)ceil_div64(M8, 4);
@@ -1208,6 +1214,7 @@ extern "C" int ddsp_unit2ctrl_fwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
                           n_mix, B, Fr, in);
     if (rc) return rc;
     DDSP_REQUIRE(ctx, ctrl, "ddsp_unit2ctrl_fwd: null ctrl");
+    if ((rc = ddsp_take_dev_error(ctx))) return rc;
     if (B == 0) return DDSP_OK;
     hipStream_t st = (hipStream_t)stream;
     DDSP_HIP(ctx, hipSetDevice(ctx->device));
@@ -1234,6 +1241,7 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
                           n_mix, B, Fr, in);
     if (rc) return rc;
     DDSP_REQUIRE(ctx, d_ctrl && grads_host, "ddsp_unit2ctrl_bwd: null argument");
+    if ((rc = ddsp_take_dev_error(ctx))) return rc;
     if (B == 0) return DDSP_OK;
     hipStream_t st = (hipStream_t)stream;
     DDSP_HIP(ctx, hipSetDevice(ctx->device));
@@ -1405,7 +1413,7 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
     DDSP_HIP(ctx, hipMemcpyAsync(G(volume_b), G(f0_b), D * sizeof(float), hipMemcpyDeviceToDevice, st));
     DDSP_HIP(ctx, hipMemsetAsync(G(spk_table), 0, (size_t)w.n_spk * D * sizeof(float), st));
     hipLaunchKernelGGL(spk_embed_bwd_kernel, dim3((unsigned)B), dim3(D), 0, st, dX, B, (int)Fr, in.spk_id, in.n_spk_id,
-                       in.mix, G(spk_table));
+                       in.mix, G(spk_table), w.n_spk);
     if ((rc = colsum(ctx, st, dX, D, M, D, nullptr, 0, cpart, G(prenet_conv2_b)))) return rc;
     // ---- prenet conv2: weight gradient by taps (shifted copies of its input), input gradient as the flipped conv ----
     for (int tap = 0; tap < 3; ++tap) {

@@ -19,6 +19,7 @@ COMB_NONE, COMB_SINC, COMB_SINC_GATED = 0, 1, 2
 FIR_ALLPASS, FIR_DYNAMIC, FIR_STATIC = 0, 1, 2
 EXC_AUDIO, EXC_UNIT_NOISE, EXC_GENERATE = 0, 1, 2
 FIR_FP32, FIR_SPLIT_BF16 = 0, 3   # ddsp_ltv_fir `math` (include/ddsp_amd.h)
+MATH_FP32, MATH_SPLIT_BF16 = 0, 3  # ddsp_ctx_set_math
 
 _c = ctypes
 _vp, _i64, _u64, _int, _f32 = _c.c_void_p, _c.c_int64, _c.c_uint64, _c.c_int, _c.c_float
@@ -55,6 +56,9 @@ SIGNATURES = {
     "ddsp_ctx_destroy": (_int, [_vp]),
     "ddsp_last_error": (_c.c_char_p, [_vp]),
     "ddsp_ctx_reserve": (_int, [_vp, _u64]),
+    "ddsp_ctx_poll_error": (_int, [_vp]),
+    "ddsp_ctx_set_math": (_int, [_vp, _int]),
+    "ddsp_ctx_get_math": (_int, [_vp]),
     "ddsp_upsample": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _int, _vp]),
     "ddsp_phase_scan": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "ddsp_fir_from_ctrl": (_int, [_vp, _vp, _int, _vp, _i64, _int, _vp, _i64, _int, _vp]),
@@ -163,6 +167,21 @@ class Context:
         """After a HIP graph has captured calls made through this context: refuse every further eager call, so that
         nothing can regrow or overwrite the scratch memory the captured kernels point into."""
         self._frozen = True
+
+    def poll_error(self):
+        """Raises ValueError if a kernel of an earlier call met a device-side contract violation (a speaker id outside
+        the table); synchronise the stream first to be sure the call has run."""
+        self._check(self.lib.ddsp_ctx_poll_error(self.handle), "ddsp_ctx_poll_error")
+
+    # -- product arithmetic of the inference contractions ---------------------------------------
+    @property
+    def math(self):
+        return self.lib.ddsp_ctx_get_math(self.handle)
+
+    def set_math(self, math):
+        """MATH_SPLIT_BF16 (default) or MATH_FP32: `ddsp_ctx_set_math`; the model forwards pass the same value to
+        `ddsp_ltv_fir`."""
+        self._check(self.lib.ddsp_ctx_set_math(self.handle, int(math)), "ddsp_ctx_set_math")
 
     # -- measurement ---------------------------------------------------------------------------
     def profile_begin(self, families=None):

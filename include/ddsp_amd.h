@@ -38,6 +38,22 @@ const char* ddsp_last_error(const ddsp_ctx* ctx);
 /* Pre-size the scratch arena (bytes).  Optional; calls grow it on demand (with a device sync). */
 int ddsp_ctx_reserve(ddsp_ctx* ctx, uint64_t bytes);
 int ddsp_abi_version(void);
+/* Device-side contract violations cannot fail the call that launched them (nothing synchronises): a kernel that meets
+ * one - a speaker id outside [1, n_spk], where the reference's nn.Embedding raises - skips the access and sets a flag in
+ * host-mapped memory.  The next ddsp_unit2ctrl_* call on the context, or this function (call it after synchronising the
+ * stream), returns DDSP_ERR_ARG once and clears the flag. */
+int ddsp_ctx_poll_error(ddsp_ctx* ctx);
+/* Product arithmetic of the INFERENCE contractions that have both forms (the Linear / conv GEMMs of ddsp_unit2ctrl_fwd,
+ * the inverse-DFT GEMMs of ddsp_fir_from_ctrl; ddsp_ltv_fir takes its own `math` argument):
+ *   DDSP_MATH_SPLIT_BF16 (default): every fp32 product from three bf16 matrix products (hi*hi + hi*lo + lo*hi), fp32
+ *                         accumulation, ~4e-6 relative error per contraction - narrower than the reference's fp32;
+ *   DDSP_MATH_FP32:       fp32 matrix products (v_mfma_f32_*_f32), ~3e-7 - the reference's precision class.
+ * Training (ddsp_unit2ctrl_bwd and every *_bwd entry point) always uses fp32 products.  Small problems that do not
+ * reach the LDS-DMA GEMM kernel run fp32 products in either mode. */
+#define DDSP_MATH_FP32 0
+#define DDSP_MATH_SPLIT_BF16 3
+int ddsp_ctx_set_math(ddsp_ctx* ctx, int math);
+int ddsp_ctx_get_math(const ddsp_ctx* ctx);
 
 /* ---- a1: frame -> sample linear upsampler ------------------------------------------------- */
 /* replaces ddsp/core.py:7-21 `upsample(signal(B,Fr,C), factor)`; out (B, Fr*hop, C):

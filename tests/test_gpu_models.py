@@ -294,3 +294,107 @@ def test_full_bench_batch_against_oracle(dev, lib_path):
     errs = (rms(sig.cpu() - sig_o), rms(hm.cpu() - hm_o), rms(nz.cpu() - nz_o))
     assert max(errs) < GATE, errs
     assert rms(sig_o) > 1e-3
+
+
+def test_full_bench_batch_both_math_modes(dev, lib_path):
+    """`ddsp_ctx_set_math`: the 64 x 172 CombSub batch with every contraction on the fp32 matrix pipe (the reference's
+    precision class) and with split-bf16x3 products (the default), both against the CPU oracle on 8 of the 64 clips.  The
+    fp32 mode must be clearly tighter than the gate; the two modes differ from each other by what the split costs."""
+    import hipddsp
+    model, cfg = synthetic.build_model("CombSub", seed=9)
+    sd = model.state_dict()
+    B, Fr = 64, 172
+    inp = synthetic.make_inputs(902, B, Fr)
+    pick = list(range(3, B, 8))
+    with torch.no_grad():
+        want = OS.combsub_forward(sd, cfg, inp["units"][pick], inp["f0"][pick], inp["volume"][pick],
+                                  inp["spk_id"][pick], infer=True, noise=inp["noise"][pick])[0]
+    model = model.to(dev).eval()
+    d = _to(inp, dev)
+    ctx = hipddsp.context_for(dev)
+    assert ctx.math == hipddsp.MATH_SPLIT_BF16                     # the library's default
+    got = {}
+    try:
+        for mode in (hipddsp.MATH_FP32, hipddsp.MATH_SPLIT_BF16):
+            ctx.set_math(mode)
+            assert ctx.math == mode
+            with torch.no_grad():
+                got[mode] = model(d["units"], d["f0"], d["volume"], d["spk_id"], infer=True, noise=d["noise"])[0]
+    finally:
+        ctx.set_math(hipddsp.MATH_SPLIT_BF16)
+    e32 = rms(got[hipddsp.MATH_FP32][pick].cpu() - want)
+    e16 = rms(got[hipddsp.MATH_SPLIT_BF16][pick].cpu() - want)
+    assert e32 < 2e-5 and e16 < GATE, (e32, e16)
+    assert e32 <= e16 * 1.05, (e32, e16)
+    diff = rms(got[hipddsp.MATH_FP32] - got[hipddsp.MATH_SPLIT_BF16])
+    assert 0 < diff < 5e-5, diff                                    # different kernels did run, and agree
+    with pytest.raises(ValueError):
+        ctx.set_math(2)
+
+
+def test_sins256_bench_batch_against_oracle(dev, lib_path):
+    """BASELINE config #3 at its full size: Sins with 256 harmonics, 64 clips x 172 frames (the large-batch kernel
+    choices of the control network, the bank and the FIRs), 8 of the 64 clips against the CPU oracle."""
+    model, cfg = synthetic.build_model("Sins256", seed=11)
+    sd = model.state_dict()
+    B, Fr = 64, 172
+    inp = synthetic.make_inputs(903, B, Fr)
+    inp["f0"][5, 40:60, 0] = 700.0                                  # harmonics crossing sr/2 inside the bank
+    pick = list(range(5, B, 8))
+    with torch.no_grad():
+        sig_o, ph_o, (hm_o, nz_o), _ = OS.sins_forward(sd, cfg, inp["units"][pick], inp["f0"][pick],
+                                                       inp["volume"][pick], inp["spk_id"][pick], infer=True,
+                                                       noise=inp["noise"][pick])
+    model = model.to(dev).eval()
+    d = _to(inp, dev)
+    with torch.no_grad():
+        sig, ph, (hm, nz) = model(d["units"], d["f0"], d["volume"], d["spk_id"], infer=True, noise=d["noise"])
+    assert sig.shape == (B, Fr * 512) and ph.shape == (B, Fr * 512, 1)
+    errs = (rms(sig[pick].cpu() - sig_o), rms(hm[pick].cpu() - hm_o), rms(nz[pick].cpu() - nz_o))
+    assert max(errs) < GATE, errs
+    assert rms(sig_o) > 1e-3
+
+
+def test_speaker_id_out_of_range_is_reported(dev, lib_path):
+    """a speaker id outside [1, n_spk] must neither read outside the table (forward) nor write outside the
+    gradient table (backward); the reference's nn.Embedding raises.  The kernels skip the access and raise a device-side
+    flag that the next call (or Context.poll_error) turns into ValueError."""
+    import hipddsp
+    model, cfg = synthetic.build_model("CombSub", seed=5, device=dev)
+    B, Fr = 3, 12
+    d = _to(synthetic.make_inputs(6, B, Fr), dev)
+    ctx = hipddsp.context_for(dev)
+    with torch.no_grad():
+        good = model(d["units"], d["f0"], d["volume"], d["spk_id"], noise=d["noise"])[0]
+    for bad in (0, cfg["n_spk"] + 1, -7, 10 ** 12):
+        ids = d["spk_id"].clone()
+        ids[1, 0] = bad
+        with torch.no_grad():
+            out = model(d["units"], d["f0"], d["volume"], ids, noise=d["noise"])[0]
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        assert torch.equal(out[0], good[0]) and torch.equal(out[2], good[2])      # the other rows are untouched
+        with pytest.raises(ValueError, match="spk_id"):
+            ctx.poll_error()
+        ctx.poll_error()                                                            # reported once, then clear
+    # the next unit2ctrl call reports a flag nobody polled
+    ids = d["spk_id"].clone()
+    ids[0, 0] = 0
+    with torch.no_grad():
+        model(d["units"], d["f0"], d["volume"], ids, noise=d["noise"])
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="spk_id"):
+        model(d["units"], d["f0"], d["volume"], d["spk_id"], noise=d["noise"])
+    # backward: no write outside the gradient table (guard elements around a copy of the table's gradient)
+    model.train()
+    ids = d["spk_id"].clone()
+    ids[2, 0] = cfg["n_spk"] + 1
+    sig = model(d["units"], d["f0"], d["volume"], ids, infer=False, noise=d["noise"])[0]
+    sig.square().mean().backward()
+    torch.cuda.synchronize()
+    g = model.unit2ctrl.spk_embed.weight.grad
+    assert torch.isfinite(g).all()
+    rows_hit = (g.abs().sum(dim=1) > 0).nonzero().flatten().tolist()
+    assert sorted(rows_hit) == sorted({int(ids[0, 0]) - 1, int(ids[1, 0]) - 1}), rows_hit
+    with pytest.raises(ValueError, match="spk_id"):
+        ctx.poll_error()

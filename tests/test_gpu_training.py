@@ -204,3 +204,38 @@ def test_train_steps_against_reference_run(dev, lib_path):
     assert np.allclose(d0, z["deltanorm0"], rtol=2e-2, atol=1e-7), np.abs(d0 / z["deltanorm0"] - 1).max()
     dall = np.array([float((p.detach() - before[n]).norm()) for n, p in model.named_parameters()])
     assert np.allclose(dall, z["deltanorm_all"], rtol=0.5, atol=1e-7)
+
+
+def test_train_step_bench_batch_against_autograd(dev, lib_path):
+    """BASELINE config #4 at its full size: one CombSub training step on 32 clips x 172 frames (the large-batch kernel
+    choices of the forward, the loss and the backward) against PyTorch autograd through the CPU oracle: loss, and the
+    gradient norms of a parameter from every part of the network.  Exact phase (infer=True), so that single-ulp flips of
+    the train-mode phase do not blur the comparison (test_combsub_train_step_matches_autograd covers that mode)."""
+    from ddsp.loss import RSSLoss
+    model, cfg = synthetic.build_model("CombSub", seed=17)
+    B, Fr = 32, 172
+    inp = synthetic.make_inputs(777, B, Fr)
+    rng = np.random.Generator(np.random.PCG64(12))
+    target = torch.from_numpy((0.1 * rng.standard_normal((B, Fr * 512))).astype(np.float32))
+    scales = [300, 777, 1531, 2047]
+    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+    loss_o, grads_o, _ = _oracle_step(model.state_dict(), cfg, inp, target, scales, infer=True)
+    model = model.to(dev).train()
+    crit = RSSLoss(256, 2048, 4, device=dev)
+    d = {k: v.to(dev) for k, v in inp.items()}
+    sig = model(d["units"], d["f0"], d["volume"], d["spk_id"], infer=True, noise=d["noise"])[0]
+    crit.set_scales(scales)
+    loss = crit(sig, target.to(dev))
+    loss.backward()
+    assert abs(float(loss.detach()) - loss_o) < 5e-5 * abs(loss_o), (float(loss.detach()), loss_o)
+    watch = ["unit2ctrl.unit_prenet.1.weight", "unit2ctrl.unit_prenet.4.weight", "unit2ctrl.f0_embed.weight",
+             "unit2ctrl.spk_embed.weight", "unit2ctrl.dec_post.0.net.0.attn.to_q.weight",
+             "unit2ctrl.dec_post.0.net.1.attn.to_out.weight", "unit2ctrl.dec_post.0.net.2.local_mixer.net.4.weight",
+             "unit2ctrl.dec_post.0.net.2.local_mixer.net.6.weight", "unit2ctrl.dec_post.2.weight_v"]
+    named = dict(model.named_parameters())
+    missing = [n for n in watch if n not in named]
+    assert not missing, (missing, list(named)[:80])
+    errs = {n: _rel(named[n].grad.cpu(), grads_o[n]) for n in watch}
+    assert max(errs.values()) < 2e-2, errs
+    all_errs = sorted(((_rel(p.grad.cpu(), grads_o[n]), n) for n, p in model.named_parameters()), reverse=True)
+    assert sum(e for e, _ in all_errs) / len(all_errs) < 5e-3, all_errs[:5]
