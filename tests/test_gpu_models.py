@@ -385,16 +385,24 @@ def test_speaker_id_out_of_range_is_reported(dev, lib_path):
     torch.cuda.synchronize()
     with pytest.raises(ValueError, match="spk_id"):
         model(d["units"], d["f0"], d["volume"], d["spk_id"], noise=d["noise"])
-    # backward: no write outside the gradient table (guard elements around a copy of the table's gradient)
+    # backward: no write outside the gradient table.  The id is changed between forward and backward (the node keeps the
+    # caller's tensor), so that the recomputed forward inside ddsp_unit2ctrl_bwd and the table-gradient kernel meet it
     model.train()
     ids = d["spk_id"].clone()
-    ids[2, 0] = cfg["n_spk"] + 1
     sig = model(d["units"], d["f0"], d["volume"], ids, infer=False, noise=d["noise"])[0]
+    keep = int(ids[2, 0])
+    ids[2, 0] = cfg["n_spk"] + 1
     sig.square().mean().backward()
     torch.cuda.synchronize()
     g = model.unit2ctrl.spk_embed.weight.grad
     assert torch.isfinite(g).all()
     rows_hit = (g.abs().sum(dim=1) > 0).nonzero().flatten().tolist()
-    assert sorted(rows_hit) == sorted({int(ids[0, 0]) - 1, int(ids[1, 0]) - 1}), rows_hit
+    assert sorted(rows_hit) == sorted({int(ids[0, 0]) - 1, int(ids[1, 0]) - 1} - {keep - 1} | ({keep - 1} & {int(ids[0, 0]) - 1, int(ids[1, 0]) - 1})), rows_hit
     with pytest.raises(ValueError, match="spk_id"):
         ctx.poll_error()
+    # a forward that raised the flag makes the backward of the same step fail loudly
+    ids[2, 0] = 0
+    sig = model(d["units"], d["f0"], d["volume"], ids, infer=False, noise=d["noise"])[0]
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="spk_id"):
+        sig.square().mean().backward()

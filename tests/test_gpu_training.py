@@ -207,35 +207,52 @@ def test_train_steps_against_reference_run(dev, lib_path):
 
 
 def test_train_step_bench_batch_against_autograd(dev, lib_path):
-    """BASELINE config #4 at its full size: one CombSub training step on 32 clips x 172 frames (the large-batch kernel
-    choices of the forward, the loss and the backward) against PyTorch autograd through the CPU oracle: loss, and the
-    gradient norms of a parameter from every part of the network.  Exact phase (infer=True), so that single-ulp flips of
-    the train-mode phase do not blur the comparison (test_combsub_train_step_matches_autograd covers that mode)."""
+    """BASELINE config #4 at its full size: CombSub training on 32 clips x 172 frames (the large-batch kernel choices of
+    the forward, the loss and the backward) against PyTorch autograd through the CPU oracle.
+
+    The composition loss-gradient(signal) is too ill-conditioned to compare end to end at this size: the device signal
+    differs from the oracle's by 8e-5 relative and dL/dsignal evaluated at the two signals then differs by a relative 1.2
+    (1/S_p in near-empty bins and the sign of the log term; tools/diag_train_b32.py, at B=4: 9e-6 -> 2.7e-2).  So the three
+    stages are held to the oracle separately, each on identical inputs: the loss value; the loss kernel's gradient at the
+    ORACLE's signal against an fp64 evaluation; the whole device backward fed with the ORACLE's dL/dsignal against the
+    oracle's parameter gradients."""
+    import hipddsp
     from ddsp.loss import RSSLoss
     model, cfg = synthetic.build_model("CombSub", seed=17)
+    sd0 = model.state_dict()
     B, Fr = 32, 172
     inp = synthetic.make_inputs(777, B, Fr)
     rng = np.random.Generator(np.random.PCG64(12))
     target = torch.from_numpy((0.1 * rng.standard_normal((B, Fr * 512))).astype(np.float32))
     scales = [300, 777, 1531, 2047]
-    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
-    loss_o, grads_o, _ = _oracle_step(model.state_dict(), cfg, inp, target, scales, infer=True)
+    import os
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    names = [n for n, _ in model.named_parameters()]
+    params = {k: sd0[k].clone().requires_grad_(True) for k in names}
+    sd = dict(sd0)
+    sd.update(params)
+    sig_o = OS.combsub_forward(sd, cfg, inp["units"], inp["f0"], inp["volume"], inp["spk_id"], infer=True,
+                               noise=inp["noise"])[0]
+    sig_o.retain_grad()
+    loss_o = OL.rss_loss(sig_o, target, scales)
+    loss_o.backward()
+    x64 = sig_o.detach().double().requires_grad_(True)
+    OL.rss_loss(x64, target.double(), scales).backward()
+    cpu_err = _rel(sig_o.grad, x64.grad)
+
     model = model.to(dev).train()
-    crit = RSSLoss(256, 2048, 4, device=dev)
     d = {k: v.to(dev) for k, v in inp.items()}
     sig = model(d["units"], d["f0"], d["volume"], d["spk_id"], infer=True, noise=d["noise"])[0]
+    assert _rel(sig.detach().cpu(), sig_o.detach()) < 5e-4
+    crit = RSSLoss(256, 2048, 4, device=dev)
     crit.set_scales(scales)
-    loss = crit(sig, target.to(dev))
-    loss.backward()
-    assert abs(float(loss.detach()) - loss_o) < 5e-5 * abs(loss_o), (float(loss.detach()), loss_o)
-    watch = ["unit2ctrl.unit_prenet.1.weight", "unit2ctrl.unit_prenet.4.weight", "unit2ctrl.f0_embed.weight",
-             "unit2ctrl.spk_embed.weight", "unit2ctrl.dec_post.0.net.0.attn.to_q.weight",
-             "unit2ctrl.dec_post.0.net.1.attn.to_out.weight", "unit2ctrl.dec_post.0.net.2.local_mixer.net.4.weight",
-             "unit2ctrl.dec_post.0.net.2.local_mixer.net.6.weight", "unit2ctrl.dec_post.2.weight_v"]
-    named = dict(model.named_parameters())
-    missing = [n for n in watch if n not in named]
-    assert not missing, (missing, list(named)[:80])
-    errs = {n: _rel(named[n].grad.cpu(), grads_o[n]) for n in watch}
-    assert max(errs.values()) < 2e-2, errs
-    all_errs = sorted(((_rel(p.grad.cpu(), grads_o[n]), n) for n, p in model.named_parameters()), reverse=True)
-    assert sum(e for e, _ in all_errs) / len(all_errs) < 5e-3, all_errs[:5]
+    loss = crit(sig.detach(), target.to(dev))
+    assert abs(float(loss) - float(loss_o.detach())) < 5e-5 * float(loss_o.detach()), (float(loss), float(loss_o.detach()))
+    # the loss kernel at full size, at the oracle's signal
+    _, g = hipddsp.context_for(dev).rss_loss(sig_o.detach().to(dev), target.to(dev), scales, want_grad=True)
+    assert _rel(g.cpu(), x64.grad) < max(3 * cpu_err, 4e-3), (_rel(g.cpu(), x64.grad), cpu_err)
+    # the device backward at full size, fed with the oracle's loss gradient
+    sig.backward(sig_o.grad.to(dev))
+    errs = sorted(((_rel(p.grad.cpu(), params[n].grad), n) for n, p in model.named_parameters()), reverse=True)
+    assert errs[0][0] < 1e-2, errs[:5]
+    assert sum(e for e, _ in errs) / len(errs) < 5e-3, errs[:5]
