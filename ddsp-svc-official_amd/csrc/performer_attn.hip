@@ -23,6 +23,8 @@
 // same rows at about the same time, so three of the four reads hit the CU's L1.  All arithmetic fp32.
 #include "performer_attn.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int H = 8, DH = 64, INNER = 512, NF = 266;
@@ -70,16 +72,10 @@ __device__ __forceinline__ float group_max(float x) {
     return x;
 }
 
-__global__ void __launch_bounds__(256, 4) performer_kv_kernel(const float* __restrict__ k, const float* __restrict__ v,
-                                                              const float* __restrict__ P, int Fr,
-                                                              float* __restrict__ ctxT, float* __restrict__ ks) {
-    // 1-D grid, XCD-aware: workgroups id and id+8 share an XCD (and its L2), so all feature tiles of one
-    // (utterance, head) - which re-read the same k and v rows - are dealt to ONE XCD (id & 7)
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int grp = slot % KV_GROUPS, bh = (slot / KV_GROUPS) * 8 + xcd, b = bh / H, h = bh % H;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int jt = 4 * grp + wave;
-    if (jt >= NJT) return;
+__device__ __forceinline__ void performer_kv_item(const float* __restrict__ k, const float* __restrict__ v,
+                                                  const float* __restrict__ P, int Fr, float* __restrict__ ctxT,
+                                                  float* __restrict__ ks, int bh, int jt) {
+    const int b = bh / H, h = bh % H;
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const int j = 16 * jt + c;                  // this lane's feature (column of S, row of ctx)
     // out-of-range rows are CLAMPED (finite garbage), and switched off through the accumulator's initial value
@@ -169,15 +165,46 @@ __global__ void __launch_bounds__(256, 4) performer_kv_kernel(const float* __res
     }
 }
 
-__global__ void __launch_bounds__(256, 4) performer_q_kernel(const float* __restrict__ q, const float* __restrict__ P,
-                                                             const float* __restrict__ ctxT, const float* __restrict__ ks,
-                                                             int Fr, int n_grp, float* __restrict__ attn) {
-    // XCD-aware 1-D grid (see performer_kv_kernel): the frame tiles of one (utterance, head) share ctx / ks / P
+__global__ void __launch_bounds__(256, 4) performer_kv_kernel(const float* __restrict__ k, const float* __restrict__ v,
+                                                              const float* __restrict__ P, int Fr,
+                                                              float* __restrict__ ctxT, float* __restrict__ ks) {
+    // 1-D grid, XCD-aware: workgroups id and id+8 share an XCD (and its L2), so all feature tiles of one
+    // (utterance, head) - which re-read the same k and v rows - are dealt to ONE XCD (id & 7)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int grp = slot % n_grp, bh = (slot / n_grp) * 8 + xcd, b = bh / H, h = bh % H;
+    const int grp = slot % KV_GROUPS, bh = (slot / KV_GROUPS) * 8 + xcd;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ft = 4 * grp + wave;
-    if (16 * ft >= Fr) return;
+    const int jt = 4 * grp + wave;
+    if (jt >= NJT) return;
+    performer_kv_item(k, v, P, Fr, ctxT, ks, bh, jt);
+}
+
+// Measurement variant (DDSP_ATTN_PERSIST=1, tools/attn_dispatch.py): as many waves as the chip holds at once, each
+// pulling (utterance-head, tile) items from a counter until none is left - no partly filled last round.  Consecutive
+// item numbers are consecutive tiles of one (utterance, head), so the waves of a workgroup still share rows in L1.
+__global__ void __launch_bounds__(256, 4) performer_kv_persist_kernel(const float* __restrict__ k, const float* __restrict__ v,
+                                                                      const float* __restrict__ P, int Fr,
+                                                                      float* __restrict__ ctxT, float* __restrict__ ks,
+                                                                      int* __restrict__ counter, int n_items) {
+    // n_items = workgroup items per XCD; counter[xcd]: the same (utterance-head -> XCD, 4 neighbouring tiles per
+    // workgroup) mapping as the grid version, only pulled instead of dispatched
+    const int xcd = blockIdx.x & 7;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ int s_item;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_item = atomicAdd(counter + xcd, 1);
+        __syncthreads();
+        const int slot = s_item;
+        if (slot >= n_items) return;
+        const int grp = slot % KV_GROUPS, bh = (slot / KV_GROUPS) * 8 + xcd, jt = 4 * grp + wave;
+        if (jt < NJT) performer_kv_item(k, v, P, Fr, ctxT, ks, bh, jt);
+    }
+}
+
+__device__ __forceinline__ void performer_q_item(const float* __restrict__ q, const float* __restrict__ P,
+                                                 const float* __restrict__ ctxT, const float* __restrict__ ks, int Fr,
+                                                 float* __restrict__ attn, int bh, int ft) {
+    const int b = bh / H, h = bh % H;
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const int frame = 16 * ft + c;              // this lane's frame (column of S^T and of out^T)
     float qb[16];
@@ -269,9 +296,58 @@ __global__ void __launch_bounds__(256, 4) performer_q_kernel(const float* __rest
     }
 }
 
+__global__ void __launch_bounds__(256, 4) performer_q_kernel(const float* __restrict__ q, const float* __restrict__ P,
+                                                             const float* __restrict__ ctxT, const float* __restrict__ ks,
+                                                             int Fr, int n_grp, float* __restrict__ attn) {
+    // XCD-aware 1-D grid (see performer_kv_kernel): the frame tiles of one (utterance, head) share ctx / ks / P
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int grp = slot % n_grp, bh = (slot / n_grp) * 8 + xcd;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ft = 4 * grp + wave;
+    if (16 * ft >= Fr) return;
+    performer_q_item(q, P, ctxT, ks, Fr, attn, bh, ft);
+}
+
+__global__ void __launch_bounds__(256, 4) performer_q_persist_kernel(const float* __restrict__ q, const float* __restrict__ P,
+                                                                     const float* __restrict__ ctxT,
+                                                                     const float* __restrict__ ks, int Fr,
+                                                                     float* __restrict__ attn, int* __restrict__ counter,
+                                                                     int n_items, int n_ft) {
+    const int xcd = blockIdx.x & 7;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_grp = (n_ft + 3) / 4;
+    __shared__ int s_item;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_item = atomicAdd(counter + xcd, 1);
+        __syncthreads();
+        const int slot = s_item;
+        if (slot >= n_items) return;
+        const int grp = slot % n_grp, bh = (slot / n_grp) * 8 + xcd, ft = 4 * grp + wave;
+        if (ft < n_ft) performer_q_item(q, P, ctxT, ks, Fr, attn, bh, ft);
+    }
+}
+
 }  // namespace
 
+// measurement switch: DDSP_ATTN_PERSIST=1 runs the persistent variants (a device counter per launch, zeroed on the stream)
+static int* persist_counter() {
+    static int* ctr = nullptr;
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("DDSP_ATTN_PERSIST");
+        on = (e && e[0] == '1') ? 1 : 0;
+        if (on && hipMalloc((void**)&ctr, 128) != hipSuccess) on = 0;
+    }
+    return on ? ctr : nullptr;
+}
+
 void performer_kv(hipStream_t st, const float* k, const float* v, const float* P, int B, int Fr, float* ctxT, float* ks) {
+    if (int* ctr = persist_counter()) {
+        (void)hipMemsetAsync(ctr, 0, 32, st);
+        hipLaunchKernelGGL(performer_kv_persist_kernel, dim3(1024), dim3(256), 0, st, k, v, P, Fr, ctxT, ks, ctr, KV_GROUPS * B);
+        return;
+    }
     // B*H is a multiple of 8, so the XCD-aware decode of the 1-D grid covers every (head, tile group) exactly once
     hipLaunchKernelGGL(performer_kv_kernel, dim3((unsigned)(KV_GROUPS * B * H)), dim3(256), 0, st, k, v, P, Fr, ctxT, ks);
 }
@@ -279,5 +355,12 @@ void performer_kv(hipStream_t st, const float* k, const float* v, const float* P
 void performer_q(hipStream_t st, const float* q, const float* P, const float* ctxT, const float* ks, int B, int Fr,
                  float* attn) {
     const int n_grp = ((Fr + 15) / 16 + 3) / 4;
+    if (int* ctr = persist_counter()) {
+        const int n_ft = (Fr + 15) / 16;
+        (void)hipMemsetAsync(ctr + 8, 0, 32, st);
+        hipLaunchKernelGGL(performer_q_persist_kernel, dim3(1024), dim3(256), 0, st, q, P, ctxT, ks, Fr, attn, ctr + 8,
+                           n_grp * B, n_ft);
+        return;
+    }
     hipLaunchKernelGGL(performer_q_kernel, dim3((unsigned)(n_grp * B * H)), dim3(256), 0, st, q, P, ctxT, ks, Fr, n_grp, attn);
 }

@@ -840,7 +840,7 @@ struct LayerBufs {
     float *x_in, *y, *q, *k, *v, *qf, *kf, *ks, *cx, *dinv, *attn, *x_mid, *y2, *g1, *glu, *pre, *dwo, *x_out;
 };
 struct U2CBufs {
-    float *w1, *w2, *wh, *wqkv, *bqkv, *wglu, *bglu, *wdw, *t1, *t2, *gst, *y_final;
+    float *w1, *w2, *wh, *wqkv, *bqkv, *wglu, *bglu, *wdw, *p3, *t1, *t2, *gst, *y_final;
     LayerBufs l[3];
 };
 
@@ -872,6 +872,7 @@ static void plan_forward(Arena& a, U2CBufs& bf, const ddsp_u2c_weights& w, int64
     bf.wglu = a.get((size_t)3 * 2 * INNER * D);    // pw1 re-ordered for the fused GLU epilogue (inference)
     bf.bglu = a.get((size_t)3 * 2 * INNER);
     bf.wdw = a.get((size_t)3 * DWK * INNER);         // depthwise taps as [tap][channel]
+    bf.p3 = a.get((size_t)3 * PERFORMER_P3_BYTES / 4);  // projection matrices as bf16 pieces (split-bf16 attention)
     bf.t1 = a.get(M * D);
     bf.t2 = a.get(M * D);
     bf.gst = a.get((size_t)B * 4 * 2);
@@ -885,7 +886,7 @@ static void plan_forward(Arena& a, U2CBufs& bf, const ddsp_u2c_weights& w, int64
         L.qf = a.get(M8 * LDF);
         L.kf = a.get(M8 * LDF);
         L.ks = a.get((size_t)B * H * PERFORMER_KS_STRIDE);           // (the fused inference kernels pad features to 272)
-        L.cx = a.get((size_t)B * H * PERFORMER_LDJ * DH);
+        L.cx = a.get((size_t)B * H * (PERFORMER_CTXS_FLOATS > PERFORMER_LDJ * DH ? PERFORMER_CTXS_FLOATS : PERFORMER_LDJ * DH));
         L.dinv = a.get(M8);
         L.attn = a.get(M * INNER);
         L.g1 = a.get(M * 2 * INNER);
@@ -1009,7 +1010,16 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
             PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * 3 * INNER * D, 4.0 * M * (D + 3 * INNER),
                  (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
         }
-        if (!b.pre) {
+        if (!b.pre && lin_math == DDSP_MATH_SPLIT_BF16 && B * H >= 256) {
+            // inference, split-bf16 products, enough (utterance, head) pairs to fill the chip with one workgroup each:
+            // the LDS-staged bf16 kernels (performer_attn_bf16.hip)
+            void* p3 = (char*)bf.p3 + (size_t)l * PERFORMER_P3_BYTES;
+            PROF(PF_U2C_PREP, 0, 4.0 * NF * DH + PERFORMER_P3_BYTES, performer_p3(st, L.proj, p3));
+            PROF(PF_U2C_GEMM_CTX, 4.0 * M8 * NF * DH, 4.0 * M * 2 * INNER,
+                 performer_kv_bf16(st, b.k, b.v, p3, (int)B, (int)Fr, b.cx, b.ks));
+            PROF(PF_U2C_GEMM_ATTNOUT, 4.0 * M8 * NF * DH, 4.0 * M * 2 * INNER,
+                 performer_q_bf16(st, b.q, p3, b.cx, b.ks, (int)B, (int)Fr, b.attn));
+        } else if (!b.pre) {
             // inference: fused feature maps + linear attention (performer_attn.hip); q'/k' never reach HBM
             PROF(PF_U2C_GEMM_CTX, 4.0 * M8 * NF * DH, 4.0 * M * 2 * INNER,
                  performer_kv(st, b.k, b.v, L.proj, (int)B, (int)Fr, b.cx, b.ks));

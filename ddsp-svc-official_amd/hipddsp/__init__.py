@@ -77,6 +77,7 @@ SIGNATURES = {
     "ddsp_adamw_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64]),
     "ddsp_adamw_step_multi": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _i64]),
     "ddsp_gemm_f32": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _i64, _int, _vp, _vp, _i64, _int, _int, _int, _int, _int]),
+    "ddsp_performer_attention": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _int]),
     "ddsp_profile_begin": (_int, [_vp, _u64]),
     "ddsp_profile_end": (_int, [_vp, _c.POINTER(ProfEntry), _int, _c.POINTER(_int)]),
     "ddsp_unit2ctrl_fwd": (_int, [_vp, _vp, _c.POINTER(U2CWeights), _vp, _vp, _vp, _vp, _vp, _i64,
@@ -370,6 +371,12 @@ class Context:
         self.call("ddsp_gemm_f32", A.data_ptr(), A.stride(0), int(a_k_contig), B.data_ptr(), B.stride(0), int(b_k_contig),
                   _ptr(bias), _ptr(C), N, M, N, K, int(tile), int(variant))
         return C
+
+    def performer_attention(self, q, k, v, proj, B, Fr, math=MATH_SPLIT_BF16):
+        """q, k, v (B*Fr, 512), proj (266, 64) -> merged heads (B*Fr, 512) before `to_out` (pcmer.py:69-77,123-159)."""
+        out = torch.empty(B * Fr, 512, device=q.device, dtype=torch.float32)
+        self.call("ddsp_performer_attention", _ptr(q), _ptr(k), _ptr(v), _ptr(proj), int(B), int(Fr), _ptr(out), int(math))
+        return out
 
     # -- a10 -----------------------------------------------------------------------------------
     def sins_bank(self, ctrl2d, col0, n_harmonics, f0_frames, phase, B, Fr, hop, sr):

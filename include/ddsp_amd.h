@@ -255,6 +255,15 @@ int ddsp_gemm_f32(ddsp_ctx* ctx, void* stream, const float* A, int64_t lda, int 
                   int64_t ldb, int b_k_contig, const float* bias, float* C, int64_t ldc, int M, int N, int K, int tile,
                   int variant);
 
+/* ---- building block: the linear attention of one PCmer layer without its Linear layers ------------------------------ */
+/* replaces ddsp/pcmer.py:69-77,123-159 (`softmax_kernel` feature maps + `linear_attention`, non-causal): q, k, v
+ * (B*Fr, 512) = 8 heads x 64, proj (266, 64) the layer's `projection_matrix`; out (B*Fr, 512) = the merged heads before
+ * `to_out`.  math: DDSP_MATH_FP32 (fp32 matrix products) or DDSP_MATH_SPLIT_BF16 (the feature projections from six bf16
+ * piece products - they enter an exponential -, the two context products from three).  Exposed for unit tests of the
+ * kernels ddsp_unit2ctrl_fwd runs at inference (it picks the split kernels from 32 utterances on). */
+int ddsp_performer_attention(ddsp_ctx* ctx, void* stream, const float* q, const float* k, const float* v,
+                             const float* proj, int64_t B, int64_t Fr, float* out, int math);
+
 /* ---- measurement: per-kernel-family HIP-event timing on the launch stream --------------------- */
 /* ddsp_profile_begin arms the families in `family_mask` (bit i = family i, see the name returned); while armed,
  * each kernel launch of such a family is bracketed by hipEventRecord on the caller's stream.  ddsp_profile_end
