@@ -115,6 +115,42 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// x[0..7] -> 8 bf16 hi parts (16 bytes) and 8 bf16 lo parts (16 bytes): the pre-split operand layout of the split-bf16 GEMM
+// (gemm::Args::A_split / B_split), same rounding as its in-kernel split (round to nearest even, twice)
+typedef uint32_t ddsp_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ddsp_split8(const float (&x)[8], ddsp_u32x4& hi, ddsp_u32x4& lo) {
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const f32x2v r = {x[2 * d], x[2 * d + 1]};
+        const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2v));
+        hi[d] = h;
+        const f32x2v rem = r - (f32x2v){__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u)};
+        lo[d] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rem, bf16x2v));
+    }
+}
+// The same for a lane that owns 4 of the 8 values, its lane-pair partner (lane ^ xor_mask) the other 4: the lane with the
+// first four values ends up with the group's 8 hi parts, the other with the 8 lo parts - each lane still stores 16 bytes
+// at its own slot, only the contents differ from an fp32 store.
+__device__ __forceinline__ ddsp_u32x4 ddsp_split4_pair(f32x4 v, bool second, int xor_mask) {
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+    uint32_t hi[2], lo[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const f32x2v r = {v[2 * d], v[2 * d + 1]};
+        const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2v));
+        hi[d] = h;
+        const f32x2v rem = r - (f32x2v){__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u)};
+        lo[d] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rem, bf16x2v));
+    }
+    // first lane keeps hi and needs the partner's hi; second lane keeps lo and needs the partner's lo
+    const uint32_t s0 = second ? hi[0] : lo[0], s1 = second ? hi[1] : lo[1];
+    const uint32_t r0 = (uint32_t)__shfl_xor((int)s0, xor_mask, 64), r1 = (uint32_t)__shfl_xor((int)s1, xor_mask, 64);
+    return second ? ddsp_u32x4{r0, r1, lo[0], lo[1]} : ddsp_u32x4{hi[0], hi[1], r0, r1};
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -50,7 +50,8 @@ extern "C" int ddsp_ctx_destroy(ddsp_ctx* ctx) {
 
 extern "C" int ddsp_ctx_set_math(ddsp_ctx* ctx, int math) {
     if (!ctx) return DDSP_ERR_ARG;
-    DDSP_REQUIRE(ctx, math == DDSP_MATH_FP32 || math == DDSP_MATH_SPLIT_BF16, "ddsp_ctx_set_math: unknown mode");
+    // (4: split-bf16 with the operand split inside the GEMM loops - measurement aid, see unit2ctrl.hip)
+    DDSP_REQUIRE(ctx, math == DDSP_MATH_FP32 || math == DDSP_MATH_SPLIT_BF16 || math == 4, "ddsp_ctx_set_math: unknown mode");
     ctx->math = math;
     return DDSP_OK;
 }

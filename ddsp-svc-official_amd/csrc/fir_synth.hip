@@ -190,7 +190,7 @@ extern "C" int ddsp_fir_from_ctrl(ddsp_ctx* ctx, void* stream, int mode, const f
     rc = ddsp_get_table(ctx, st, kind, M, tap_major ? 1 : 0, &tab);
     if (rc) return rc;
     float* tab_split = nullptr;   // the same table already split into bf16 hi/lo (B operand of the split-bf16 GEMM)
-    if (tap_major && ctx->math == DDSP_MATH_SPLIT_BF16 && (rc = ddsp_get_table(ctx, st, kind, M, 2, &tab_split))) return rc;
+    if (tap_major && ctx->math != DDSP_MATH_FP32 && (rc = ddsp_get_table(ctx, st, kind, M, 2, &tab_split))) return rc;
 
     ddsp_prof_begin(ctx, st, PF_FIR_ACT);
     hipLaunchKernelGGL(fir_act_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, mode, ctrl, ctrl_ld, M,
@@ -201,7 +201,7 @@ extern "C" int ddsp_fir_from_ctrl(ddsp_ctx* ctx, void* stream, int mode, const f
 
     auto run = [&](gemm::Args g, const auto& epi) {
         // (split-bf16 products like the control network's inference GEMMs: the taps then carry ~4e-6 relative error)
-        g.math = tap_major ? ctx->math : 0;   // ddsp_ctx_set_math
+        g.math = tap_major ? (ctx->math == 4 ? DDSP_MATH_SPLIT_BF16 : ctx->math) : 0;   // ddsp_ctx_set_math
         g.B_split = tab_split;
         if (tap_major)
             gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, epi);

@@ -25,6 +25,7 @@
 #pragma once
 #include "common.h"
 
+#include <stdlib.h>
 #include <type_traits>
 
 namespace gemm {
@@ -53,6 +54,9 @@ struct Args {
     // 16-byte slots of one row, so slots 2h / 2h+1 ARE the hi / lo operand of half h and the kernel does not split B.
     // Paths that do not use it (fp32 products, the register-staged kernel) read B.
     const float* B_split;
+    // A is ALREADY in that (8 hi | 8 lo) layout (written so by its producer: LayerNorm, GroupNorm+LeakyReLU, the attention
+    // kernel): with math == 3 and B_split the kernel then splits nothing (MATH = 8: bit casts and MFMAs only)
+    int A_split;
 };
 
 constexpr int BK = 32;
@@ -341,7 +345,8 @@ __global__ void __launch_bounds__(64 * NW) kernel(Args g, Epi epi) {
 // N = 256 layers, whose 128-row tilings leave a third of the CUs without work).
 // MATH: 0 = fp32 MFMA; 3 = split-bf16 (Args::math == 3: the inference GEMMs): each fp32 operand is split into bf16 hi and
 // lo pieces in registers and the product formed from 3 bf16 MFMAs (32x32x16: hi*hi + hi*lo + lo*hi) with fp32 accumulation;
-// 7 = the same with B read already split (Args::B_split); 6 = three pieces, 6 MFMAs (ddsp_gemm_f32 tile 31 only).
+// 7 = the same with B read already split (Args::B_split); 8 = A and B both already split (Args::A_split); 6 = three pieces,
+// 6 MFMAs (ddsp_gemm_f32 tile 31 only).
 // Speed and error: DESIGN.md section 9.
 template <int BM, int BN, class Epi, int NS = 3, int ABLATE = 0, int NW = 8, int A_MODE = A_PLAIN, int MATH = 0>  // ABLATE bit mask (timing experiments only): 1 no MFMA, 2 no DMA, 4 no epilogue stores, 8 no barrier
 __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ? 4 : 2)) kernel_dma(Args g, Epi epi, int tiles_m, int tiles_n, int total_tiles) {
@@ -515,10 +520,17 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ?
             for (int half = 0; half < 2; ++half) {
                 bf16x8 ap[TM][3], bp[TN][3];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) split(av[i][2 * half], av[i][2 * half + 1], ap[i]);
+                for (int i = 0; i < TM; ++i) {
+                    if constexpr (MATH == 8) {   // A arrives split (Args::A_split)
+                        ap[i][0] = __builtin_bit_cast(bf16x8, av[i][2 * half]);
+                        ap[i][1] = __builtin_bit_cast(bf16x8, av[i][2 * half + 1]);
+                    } else {
+                        split(av[i][2 * half], av[i][2 * half + 1], ap[i]);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if constexpr (MATH == 7) {   // B arrives split (Args::B_split)
+                    if constexpr (MATH == 7 || MATH == 8) {   // B arrives split (Args::B_split)
                         bp[j][0] = __builtin_bit_cast(bf16x8, bv[j][2 * half]);
                         bp[j][1] = __builtin_bit_cast(bf16x8, bv[j][2 * half + 1]);
                     } else {
@@ -663,7 +675,11 @@ inline void launch_dma(hipStream_t st, const Args& g, int batch, const Epi& epi,
 // launch_dma with the product arithmetic chosen at run time (Args::math)
 template <int BM, int BN, class Epi, int NS = 3, int NW = 8, int A_MODE = A_PLAIN>
 inline void dma_go(hipStream_t st, const Args& g, int batch, const Epi& epi, int total_override = -1) {
-    if (g.math == 3 && g.B_split) {
+    if (g.math == 3 && g.B_split && g.A_split) {
+        Args h = g;
+        h.B = g.B_split;
+        launch_dma<BM, BN, Epi, NS, 0, NW, A_MODE, 8>(st, h, batch, epi, total_override);
+    } else if (g.math == 3 && g.B_split) {
         Args h = g;
         h.B = g.B_split;
         launch_dma<BM, BN, Epi, NS, 0, NW, A_MODE, 7>(st, h, batch, epi, total_override);
@@ -737,6 +753,12 @@ inline void launch(hipStream_t st, const Args& g, int batch, const Epi& epi) {
             return;
         }
     }
+    if (g.B_split || g.A_split) {
+        // pre-split operands exist only for the DMA kernel: the caller's size predicate and this function disagree
+        fprintf(stderr, "libddsp_amd: internal error: pre-split GEMM operands on the register-staged path (M=%d N=%d K=%d)\n",
+                g.M, g.N, g.K);
+        abort();
+    }
     if (blocks(128, 64) >= 512)
         launch_tile<128, 64, A_KC, B_KC, A_MODE, Epi, 8>(st, g, batch, epi);
     else
@@ -761,6 +783,7 @@ inline Args make(const float* A, int64_t lda, const float* B, int64_t ldb, int M
     g.parent_tn = 0;
     g.math = 0;
     g.B_split = nullptr;
+    g.A_split = 0;
     return g;
 }
 

@@ -15,11 +15,11 @@ static_assert(PERFORMER_OFF_KPART32 + 9 <= PERFORMER_KS_STRIDE, "ks record too s
 constexpr int PERFORMER_CTXS_FLOATS = 9 * 512 * 4;        // per (utterance, head): ctx as bf16 hi/lo pieces in operand order
 constexpr int PERFORMER_P3_BYTES = 9 * 768 * 16;          // per layer: the scaled projection matrix as three bf16 pieces
 // p3 <- pieces of dn*log2(e)*P (266, 64), once per forward and layer
-void performer_p3(hipStream_t st, const float* P, void* p3);
+void performer_p3(hipStream_t st, const float* P0, const float* P1, const float* P2, void* p3);   // P1, P2 may be null
 void performer_kv_bf16(hipStream_t st, const float* k, const float* v, const void* p3, int B, int Fr, float* ctxS, float* ks,
                        int ablate = 0);
 void performer_q_bf16(hipStream_t st, const float* q, const void* p3, const float* ctxS, const float* ks, int B, int Fr,
-                      float* attn, int ablate = 0);
+                      float* attn, int ablate = 0, int out_split = 0);   // out_split: attn as bf16 hi/lo groups (gemm A_split)
 // ctxT[(b*8+h)][e][j] (64 x 272: the context matrix TRANSPOSED, pad features zero) and ks[(b*8+h)] (PERFORMER_KS_STRIDE floats each) from k, v (B*Fr, 512) and P (266, 64)
 void performer_kv(hipStream_t st, const float* k, const float* v, const float* P, int B, int Fr, float* ctxT, float* ks);
 // attn (B*Fr, 512) from q (B*Fr, 512), P, ctxT, ks

@@ -68,9 +68,12 @@ __device__ __forceinline__ bf16x8 as_bf(u32x4 v) { return __builtin_bit_cast(bf1
 // ---- P3: the projection matrix, scaled by dn*log2(e), as three bf16 pieces in operand order ---------------------------------
 // chunk (jt, s, piece, h, i) = 8 bf16 = pieces of PSCALE * P[32 jt + i][16 s + 8 h + 0..7] (zero rows for features >= 266);
 // flat index (((jt*4 + s)*3 + piece)*2 + h)*32 + i, 16 bytes each: PERFORMER_P3_BYTES per layer.
-__global__ void __launch_bounds__(256) performer_p3_kernel(const float* __restrict__ P, uint4* __restrict__ p3) {
-    const int t = blockIdx.x * 256 + threadIdx.x;            // (jt, s, h, i)
+__global__ void __launch_bounds__(256) performer_p3_kernel(const float* __restrict__ P0, const float* __restrict__ P1,
+                                                           const float* __restrict__ P2, uint4* __restrict__ p3) {
+    const int t = blockIdx.x * 256 + threadIdx.x;            // (jt, s, h, i); blockIdx.y = layer
     if (t >= NJT * 4 * 2 * 32) return;
+    const float* P = blockIdx.y == 0 ? P0 : (blockIdx.y == 1 ? P1 : P2);
+    p3 += (size_t)blockIdx.y * (PERFORMER_P3_BYTES / 16);
     const int i = t & 31, h = (t >> 5) & 1, s = (t >> 6) & 3, jt = t >> 8;
     const int j = 32 * jt + i;
     float x[8];
@@ -325,7 +328,7 @@ constexpr int Q_PP = 0, Q_CP = 768, Q_KS = 1280, Q_STAGE = 1344;     // 21504 by
 template <int ABL>
 __global__ void __launch_bounds__(64 * QW, 3) performer_q_bf16_kernel(const float* __restrict__ q, const uint4* __restrict__ p3,
                                                                    const uint4* __restrict__ ctxS, const float* __restrict__ ks,
-                                                                   int Fr, int n_fg, float* __restrict__ attn) {
+                                                                   int Fr, int n_fg, float* __restrict__ attn, int out_split) {
     __shared__ __attribute__((aligned(1024))) uint4 lds[2 * Q_STAGE];
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int fg = slot % n_fg, bh = (slot / n_fg) * 8 + xcd, b = bh / H, h = bh % H;
@@ -494,14 +497,22 @@ __global__ void __launch_bounds__(64 * QW, 3) performer_q_bf16_kernel(const floa
             f32x4_t res;
 #pragma unroll
             for (int e = 0; e < 4; ++e) res[e] = (o[ct][4 * g4 + e] + __shfl(cs_eps, ch + e, 64)) * dinv;
-            if (frame_ok) *(f32x4_t*)(orow + ch) = res;
+            if (out_split) {
+                // A operand of the out-projection's split-bf16 GEMM: the lane pair (lh = 0, 1) owns one group of 8 channels
+                const ddsp_u32x4 sp = ddsp_split4_pair(res, lh != 0, 32);
+                if (frame_ok) *(ddsp_u32x4*)(orow + ch) = sp;
+            } else if (frame_ok) {
+                *(f32x4_t*)(orow + ch) = res;
+            }
         }
 }
 
 }  // namespace
 
-void performer_p3(hipStream_t st, const float* P, void* p3) {
-    hipLaunchKernelGGL(performer_p3_kernel, dim3((NJT * 4 * 2 * 32 + 255) / 256), dim3(256), 0, st, P, (uint4*)p3);
+void performer_p3(hipStream_t st, const float* P0, const float* P1, const float* P2, void* p3) {
+    const unsigned layers = P2 ? 3u : (P1 ? 2u : 1u);
+    hipLaunchKernelGGL(performer_p3_kernel, dim3((NJT * 4 * 2 * 32 + 255) / 256, layers), dim3(256), 0, st, P0, P1, P2,
+                       (uint4*)p3);
 }
 
 void performer_kv_bf16(hipStream_t st, const float* k, const float* v, const void* p3, int B, int Fr, float* ctxS, float* ks,
@@ -519,18 +530,18 @@ void performer_kv_bf16(hipStream_t st, const float* k, const float* v, const voi
 }
 
 void performer_q_bf16(hipStream_t st, const float* q, const void* p3, const float* ctxS, const float* ks, int B, int Fr,
-                      float* attn, int ablate) {
+                      float* attn, int ablate, int out_split) {
     const int n_fg = ((Fr + 31) / 32 + QW - 1) / QW;
 #define Q_ABL(A)                                                                                                       \
     if (ablate == A) {                                                                                                 \
         hipLaunchKernelGGL(performer_q_bf16_kernel<A>, dim3((unsigned)(n_fg * B * H)), dim3(64 * QW), 0, st, q,        \
-                           (const uint4*)p3, (const uint4*)ctxS, ks, Fr, n_fg, attn);                                  \
+                           (const uint4*)p3, (const uint4*)ctxS, ks, Fr, n_fg, attn, out_split);                       \
         return;                                                                                                        \
     }
     Q_ABL(1) Q_ABL(2) Q_ABL(4) Q_ABL(6) Q_ABL(7)
 #undef Q_ABL
     hipLaunchKernelGGL(performer_q_bf16_kernel<0>, dim3((unsigned)(n_fg * B * H)), dim3(64 * QW), 0, st, q, (const uint4*)p3,
-                       (const uint4*)ctxS, ks, Fr, n_fg, attn);
+                       (const uint4*)ctxS, ks, Fr, n_fg, attn, out_split);
 }
 
 // ---- building block exposed for unit tests and measurements: one attention of pcmer.py:221-251 without its Linear layers ----
@@ -555,7 +566,7 @@ extern "C" int ddsp_performer_attention(ddsp_ctx* ctx, void* stream, const float
     if ((rc = ddsp_scratch_get(ctx, n_ks * sizeof(float), (void**)&ksb))) return rc;
     if ((rc = ddsp_scratch_get(ctx, PERFORMER_P3_BYTES, &p3))) return rc;
     if (math == DDSP_MATH_SPLIT_BF16) {
-        performer_p3(st, proj, p3);
+        performer_p3(st, proj, nullptr, nullptr, p3);
         ddsp_prof_begin(ctx, st, PF_U2C_GEMM_CTX);
         performer_kv_bf16(st, k, v, p3, (int)B, (int)Fr, cx, ksb, ablate);
         ddsp_prof_end(ctx, st, 4.0 * B * Fr * H * NF * DH, 4.0 * B * Fr * 2 * INNER);

@@ -24,9 +24,38 @@ constexpr int LDF = 268;      // padded leading dim of feature rows (16-byte ali
 constexpr int DWK = 31;       // depthwise kernel
 
 // ---- weight preparation --------------------------------------------------------------------------
-// conv weight (Cout, Cin, 3) -> (Cout, 3*Cin) with k = tap*Cin + c  (matches gemm A_CONV3)
+// Every GEMM weight of a forward is re-packed by ONE launch (u2c_prepare_kernel).  Each job produces groups of 8
+// consecutive k-values of one packed row and stores them either as 8 floats or, for the split-bf16 GEMMs that read B
+// already split (gemm::Args::B_split), as 8 bf16 hi parts | 8 bf16 lo parts - the same 32 bytes.
+__device__ __forceinline__ void store_group8(float* __restrict__ dst, const float (&x)[8], bool split) {
+    if (split) {
+        ddsp_u32x4 hi, lo;
+        ddsp_split8(x, hi, lo);
+        *(ddsp_u32x4*)dst = hi;
+        *(ddsp_u32x4*)(dst + 4) = lo;
+    } else {
+        *(f32x4*)dst = f32x4{x[0], x[1], x[2], x[3]};
+        *(f32x4*)(dst + 4) = f32x4{x[4], x[5], x[6], x[7]};
+    }
+}
+
+// conv weight (Cout, Cin, 3) -> (Cout, 3*Cin) with k = tap*Cin + c  (matches gemm A_CONV3); Cin % 8 == 0
 __device__ __forceinline__ void pack_conv3_body(const float* __restrict__ w, int Cout, int Cin, float* __restrict__ out,
-                                                int vb, int vgrid) {   // vb / vgrid: block id / grid size of this job
+                                                int vb, int vgrid, bool split) {   // vb / vgrid: block id / grid size of this job
+    const int64_t groups = (int64_t)Cout * 3 * (Cin / 8);
+    for (int64_t gi = (int64_t)vb * 256 + threadIdx.x; gi < groups; gi += (int64_t)vgrid * 256) {
+        const int c8 = (int)(gi % (Cin / 8));
+        const int tap = (int)((gi / (Cin / 8)) % 3);
+        const int o = (int)(gi / (3 * (Cin / 8)));
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = w[((int64_t)o * Cin + 8 * c8 + e) * 3 + tap];
+        store_group8(out + (int64_t)o * 3 * Cin + (int64_t)tap * Cin + 8 * c8, x, split);
+    }
+}
+// fp32 variant for a Cin that is only a multiple of 4 (small problems that run the register-staged kernel)
+__device__ __forceinline__ void pack_conv3_scalar_body(const float* __restrict__ w, int Cout, int Cin, float* __restrict__ out,
+                                                       int vb, int vgrid) {
     const int64_t total = (int64_t)Cout * Cin * 3;
     for (int64_t i = (int64_t)vb * 256 + threadIdx.x; i < total; i += (int64_t)vgrid * 256) {
         const int tap = (int)(i % 3);
@@ -36,32 +65,53 @@ __device__ __forceinline__ void pack_conv3_body(const float* __restrict__ w, int
     }
 }
 __global__ void __launch_bounds__(256) pack_conv3_kernel(const float* __restrict__ w, int Cout, int Cin, float* __restrict__ out) {
-    pack_conv3_body(w, Cout, Cin, out, blockIdx.x, gridDim.x);
+    pack_conv3_scalar_body(w, Cout, Cin, out, blockIdx.x, gridDim.x);
+}
+
+// a plain (rows, K) matrix copied row by row (K % 8 == 0): the out-projection and pw2 weights for the split GEMMs
+__device__ __forceinline__ void pack_copy_body(const float* __restrict__ w, int64_t n, float* __restrict__ out, int vb,
+                                               int vgrid, bool split) {
+    typedef gemm::f32x4_u v4;
+    for (int64_t gi = (int64_t)vb * 256 + threadIdx.x; gi < n / 8; gi += (int64_t)vgrid * 256) {
+        const v4 a = *(const v4*)(w + 8 * gi), c = *(const v4*)(w + 8 * gi + 4);
+        const float x[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+        store_group8(out + 8 * gi, x, split);
+    }
 }
 
 // q/k/v projections as ONE GEMM: rows [q_w; k_w; v_w] (3*512 x 256) and the three biases behind each other
 __device__ __forceinline__ void pack_qkv_body(const float* __restrict__ qw, const float* __restrict__ kw,
                                               const float* __restrict__ vw, const float* __restrict__ qb,
                                               const float* __restrict__ kb, const float* __restrict__ vb_,
-                                              float* __restrict__ w, float* __restrict__ bias, int vb, int vgrid) {
+                                              float* __restrict__ w, float* __restrict__ bias, int vb, int vgrid, bool split) {
+    typedef gemm::f32x4_u v4;
     const int n = INNER * D;
-    for (int i = vb * 256 + threadIdx.x; i < 3 * n; i += vgrid * 256) {
-        const int which = i / n, j = i - which * n;
-        w[i] = which == 0 ? qw[j] : (which == 1 ? kw[j] : vw[j]);
-        if (j < INNER) bias[which * INNER + j] = which == 0 ? qb[j] : (which == 1 ? kb[j] : vb_[j]);
+    for (int gi = vb * 256 + threadIdx.x; gi < 3 * n / 8; gi += vgrid * 256) {
+        const int i = 8 * gi, which = i / n, j = i - which * n;
+        const float* src = (which == 0 ? qw : (which == 1 ? kw : vw)) + j;
+        const v4 a = *(const v4*)src, c = *(const v4*)(src + 4);
+        const float x[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+        store_group8(w + i, x, split);
+        if (j < INNER) {
+            const float* bs = which == 0 ? qb : (which == 1 ? kb : vb_);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bias[which * INNER + j + e] = bs[j + e];
+        }
     }
 }
 
 // pw1 (1024 x 256, rows 0..511 values, 512..1023 gates of the GLU, ddsp/pcmer.py conformer conv module) re-ordered
 // for the gated-pair GEMM epilogue: packed rows 64t..64t+31 = values, 64t+32..64t+63 = gates of channels 32t..32t+31.
 __device__ __forceinline__ void pack_glu_body(const float* __restrict__ w, const float* __restrict__ bias,
-                                              float* __restrict__ wo, float* __restrict__ bo, int vb, int vgrid) {
-    for (int i = vb * 256 + threadIdx.x; i < 2 * INNER * (D / 4); i += vgrid * 256) {
-        const int p = i / (D / 4), k4 = (i % (D / 4)) * 4;
+                                              float* __restrict__ wo, float* __restrict__ bo, int vb, int vgrid, bool split) {
+    for (int i = vb * 256 + threadIdx.x; i < 2 * INNER * (D / 8); i += vgrid * 256) {
+        const int p = i / (D / 8), k8 = (i % (D / 8)) * 8;
         const int t = p >> 6, within = p & 63;
         const int src = within < 32 ? 32 * t + within : INNER + 32 * t + (within - 32);
-        *(f32x4*)(wo + (size_t)p * D + k4) = *(const f32x4*)(w + (size_t)src * D + k4);
-        if (k4 == 0) bo[p] = bias[src];
+        const f32x4 a = *(const f32x4*)(w + (size_t)src * D + k8), c = *(const f32x4*)(w + (size_t)src * D + k8 + 4);
+        const float x[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+        store_group8(wo + (size_t)p * D + k8, x, split);
+        if (k8 == 0) bo[p] = bias[src];
     }
 }
 
@@ -91,7 +141,7 @@ struct EpiSplit3 {  // column block n / 512 selects the destination matrix (q, k
 
 // W[o][:] = g[o] * v[o][:] / ||v[o]||_2   (old-style weight_norm, ddsp/unit2control.py:61); one wave per row
 __device__ __forceinline__ void weight_norm_body(const float* __restrict__ g, const float* __restrict__ v, int n_out,
-                                                 int n_in, float* __restrict__ w, int vb) {
+                                                 int n_in, float* __restrict__ w, int vb, bool split) {
     const int lane = threadIdx.x & 63;
     const int o = vb * 4 + (threadIdx.x >> 6);
     if (o >= n_out) return;
@@ -100,11 +150,20 @@ __device__ __forceinline__ void weight_norm_body(const float* __restrict__ g, co
     for (int i = lane; i < n_in; i += 64) ss = fmaf(row[i], row[i], ss);
     ss = wave_sum(ss);
     const float scale = g[o] / sqrtf(ss);
-    for (int i = lane; i < n_in; i += 64) w[(int64_t)o * n_in + i] = row[i] * scale;
+    if (n_in % 8 == 0) {
+        for (int i = 8 * lane; i < n_in; i += 512) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = row[i + e] * scale;
+            store_group8(w + (int64_t)o * n_in + i, x, split);
+        }
+    } else {
+        for (int i = lane; i < n_in; i += 64) w[(int64_t)o * n_in + i] = row[i] * scale;
+    }
 }
 __global__ void __launch_bounds__(256) weight_norm_kernel(const float* __restrict__ g, const float* __restrict__ v,
                                                           int n_out, int n_in, float* __restrict__ w) {
-    weight_norm_body(g, v, n_out, n_in, w, blockIdx.x);
+    weight_norm_body(g, v, n_out, n_in, w, blockIdx.x, false);
 }
 
 // All weight preparation of one forward in ONE launch (it used to be 6-7: two conv packs, the head's weight norm,
@@ -112,31 +171,42 @@ __global__ void __launch_bounds__(256) weight_norm_kernel(const float* __restric
 // as raw pointers on every call, so they are re-prepared every call; what can be saved is the launches.
 struct PrepArgs {
     ddsp_u2c_weights w;
-    float *w1, *w2, *wh, *wqkv, *bqkv, *wglu, *bglu, *wdw;
-    int end[6];          // one past the last block of: conv1 | conv2 | head | qkv (3 layers) | glu (3 layers, may be empty) | dw taps
-    int qkv_blocks, glu_blocks;   // blocks per layer
+    float *w1, *w2, *wh, *wqkv, *bqkv, *wglu, *bglu, *wdw, *wout, *wpw2;
+    int end[7];          // one past the last block of: conv1 | conv2 | head | qkv (3 layers) | glu (3 layers, may be empty) |
+                         // out-projection + pw2 copies (3 layers each, split mode only) | dw taps
+    int qkv_blocks, glu_blocks, copy_blocks;   // blocks per layer
+    int split;           // the packed matrices are written as bf16 hi/lo groups (gemm::Args::B_split)
 };
 __global__ void __launch_bounds__(256) u2c_prepare_kernel(PrepArgs a) {
     const int b = blockIdx.x;
+    const bool split = a.split != 0;
     if (b < a.end[0]) {
-        pack_conv3_body(a.w.prenet_conv1_w, D, a.w.n_unit, a.w1, b, a.end[0]);
+        if (a.w.n_unit % 8 == 0)
+            pack_conv3_body(a.w.prenet_conv1_w, D, a.w.n_unit, a.w1, b, a.end[0], split);
+        else
+            pack_conv3_scalar_body(a.w.prenet_conv1_w, D, a.w.n_unit, a.w1, b, a.end[0]);
     } else if (b < a.end[1]) {
-        pack_conv3_body(a.w.prenet_conv2_w, D, D, a.w2, b - a.end[0], a.end[1] - a.end[0]);
+        pack_conv3_body(a.w.prenet_conv2_w, D, D, a.w2, b - a.end[0], a.end[1] - a.end[0], split);
     } else if (b < a.end[2]) {
-        weight_norm_body(a.w.head_g, a.w.head_v, a.w.n_out, D, a.wh, b - a.end[1]);
+        weight_norm_body(a.w.head_g, a.w.head_v, a.w.n_out, D, a.wh, b - a.end[1], split);
     } else if (b < a.end[3]) {
         const int r = b - a.end[2], l = r / a.qkv_blocks;
         const ddsp_u2c_layer& L = a.w.layer[l];
         pack_qkv_body(L.q_w, L.k_w, L.v_w, L.q_b, L.k_b, L.v_b, a.wqkv + (size_t)l * 3 * INNER * D,
-                      a.bqkv + (size_t)l * 3 * INNER, r - l * a.qkv_blocks, a.qkv_blocks);
+                      a.bqkv + (size_t)l * 3 * INNER, r - l * a.qkv_blocks, a.qkv_blocks, split);
     } else if (b < a.end[4]) {
         const int r = b - a.end[3], l = r / a.glu_blocks;
         const ddsp_u2c_layer& L = a.w.layer[l];
         pack_glu_body(L.cm_pw1_w, L.cm_pw1_b, a.wglu + (size_t)l * 2 * INNER * D, a.bglu + (size_t)l * 2 * INNER,
-                      r - l * a.glu_blocks, a.glu_blocks);
+                      r - l * a.glu_blocks, a.glu_blocks, split);
+    } else if (b < a.end[5]) {
+        const int r = b - a.end[4], j = r / a.copy_blocks, l = j >> 1;     // job j: layer j/2, out-projection | pw2
+        const ddsp_u2c_layer& L = a.w.layer[l];
+        pack_copy_body((j & 1) ? L.cm_pw2_w : L.out_w, (int64_t)D * INNER, ((j & 1) ? a.wpw2 : a.wout) + (size_t)l * D * INNER,
+                       r - j * a.copy_blocks, a.copy_blocks, true);
     } else {
         // depthwise taps (512, 1, 31) -> [tap][channel], all three layers: 3 * 31 * 512 elements
-        for (int i = (b - a.end[4]) * 256 + threadIdx.x; i < 3 * DWK * INNER; i += (a.end[5] - a.end[4]) * 256) {
+        for (int i = (b - a.end[5]) * 256 + threadIdx.x; i < 3 * DWK * INNER; i += (a.end[6] - a.end[5]) * 256) {
             const int l = i / (DWK * INNER), r = i - l * DWK * INNER;
             const int t = r / INNER, c = r - t * INNER;
             a.wdw[i] = a.w.layer[l].cm_dw_w[c * DWK + t];
@@ -191,7 +261,9 @@ __global__ void __launch_bounds__(64 * GN_LANES) groupnorm_stats_kernel(const fl
 __global__ void __launch_bounds__(256) groupnorm_lrelu_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, int64_t rows, int Fr,
-                                                              float* __restrict__ out) {
+                                                              float* __restrict__ out, int split) {
+    // split != 0: the output is the A operand of a split-bf16 GEMM and is written as bf16 hi/lo groups (8 channels = two
+    // neighbouring threads; rows * 64 threads, so a pair never straddles a wave)
     const int64_t total = rows * (D / 4);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t m = i / (D / 4);
@@ -206,7 +278,10 @@ __global__ void __launch_bounds__(256) groupnorm_lrelu_kernel(const float* __res
             const float y = fmaf((v[j] - mean) * rstd, ga[j], be[j]);
             o[j] = y > 0.f ? y : 0.01f * y;
         }
-        *(f32x4*)(out + m * D + c4) = o;
+        if (split)
+            *(ddsp_u32x4*)(out + m * D + c4) = ddsp_split4_pair(o, (i & 1) != 0, 1);
+        else
+            *(f32x4*)(out + m * D + c4) = o;
     }
 }
 
@@ -263,7 +338,8 @@ __global__ void __launch_bounds__(256) embed_add_kernel(float* __restrict__ x, c
 // ---- LayerNorm over 256 channels, one wave per row (4 channels per lane) ----------------------------
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int64_t rows,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, int split) {
+    // split != 0: the row is written as bf16 hi/lo groups (A operand of a split-bf16 GEMM): lanes 2j, 2j+1 own one group
     const int lane = threadIdx.x & 63;
     const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= rows) return;
@@ -281,7 +357,10 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = fmaf(d[j] * rstd, ga[j], be[j]);
-    *(f32x4*)(out + m * D + lane * 4) = o;
+    if (split)
+        *(ddsp_u32x4*)(out + m * D + lane * 4) = ddsp_split4_pair(o, (lane & 1) != 0, 1);
+    else
+        *(f32x4*)(out + m * D + lane * 4) = o;
 }
 
 // ---- softmax-kernel feature map (ddsp/pcmer.py:123-159), in place on the projected rows ---------------
@@ -840,7 +919,7 @@ struct LayerBufs {
     float *x_in, *y, *q, *k, *v, *qf, *kf, *ks, *cx, *dinv, *attn, *x_mid, *y2, *g1, *glu, *pre, *dwo, *x_out;
 };
 struct U2CBufs {
-    float *w1, *w2, *wh, *wqkv, *bqkv, *wglu, *bglu, *wdw, *p3, *t1, *t2, *gst, *y_final;
+    float *w1, *w2, *wh, *wqkv, *bqkv, *wglu, *bglu, *wdw, *wout, *wpw2, *p3, *t1, *t2, *gst, *y_final;
     LayerBufs l[3];
 };
 
@@ -872,6 +951,8 @@ static void plan_forward(Arena& a, U2CBufs& bf, const ddsp_u2c_weights& w, int64
     bf.wglu = a.get((size_t)3 * 2 * INNER * D);    // pw1 re-ordered for the fused GLU epilogue (inference)
     bf.bglu = a.get((size_t)3 * 2 * INNER);
     bf.wdw = a.get((size_t)3 * DWK * INNER);         // depthwise taps as [tap][channel]
+    bf.wout = a.get((size_t)3 * D * INNER);          // out-projection / pw2 weights as bf16 hi/lo groups (split GEMMs)
+    bf.wpw2 = a.get((size_t)3 * D * INNER);
     bf.p3 = a.get((size_t)3 * PERFORMER_P3_BYTES / 4);  // projection matrices as bf16 pieces (split-bf16 attention)
     bf.t1 = a.get(M * D);
     bf.t2 = a.get(M * D);
@@ -932,7 +1013,9 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
     const size_t n_w1 = (size_t)D * 3 * w.n_unit, n_w2 = (size_t)D * 3 * D, n_wh = (size_t)w.n_out * D;
     // product arithmetic of the Linear / conv GEMMs (gemm::Args::math): inference uses the split-bf16 mode, the
     // training forward (activations kept for the backward pass) stays on fp32 MFMA like the backward GEMMs
-    const int lin_math = bf.l[0].pre ? 0 : ctx->math;
+    // (ctx->math 4 = split-bf16 products with every operand split inside the GEMM loops: the pre-round-2 path, kept as a
+    // measurement / bit-identity aid)
+    const int lin_math = bf.l[0].pre ? 0 : (ctx->math == 4 ? DDSP_MATH_SPLIT_BF16 : ctx->math);
     const float* zero_page = nullptr;   // source of the conv taps that fall off an utterance (LDS-DMA conv GEMM)
     if (int rc = ddsp_zero_page(ctx, &zero_page)) return rc;
     int* dev_err = nullptr;
@@ -943,6 +1026,14 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
     bool fuse_glu = !bf.l[0].pre && (int64_t)((M + 127) / 128) * (2 * INNER / 128) >= 512;
     for (int l = 0; l < 3; ++l)
         fuse_glu = fuse_glu && ((uintptr_t)w.layer[l].cm_pw1_w % 16) == 0;
+    // Split-bf16 products at a size where every GEMM of the network runs the LDS-DMA kernel: nothing is split inside the
+    // GEMM loops.  The weights are packed as bf16 hi/lo groups by the preparation launch (B_split) and the producers of
+    // the A operands (GroupNorm+LeakyReLU, the LayerNorms, the attention kernel) write them in that layout (A_split);
+    // conv1 reads the caller's fp32 units and pw2 the depthwise conv's fp32 output: those two split A in the kernel.
+    const bool presplit = lin_math == DDSP_MATH_SPLIT_BF16 && ctx->math != 4 && fuse_glu && M >= 8192 && w.n_unit % 32 == 0 &&
+                          w.n_unit + 32 <= DDSP_ZERO_FLOATS && w.n_out >= 256 && ((uintptr_t)in.units % 16) == 0;
+    const bool attn_bf16 = !bf.l[0].pre && lin_math == DDSP_MATH_SPLIT_BF16 && B * H >= 256;
+    const int asplit = presplit ? 1 : 0;
     {   // weight preparation, one launch (u2c_prepare_kernel)
         PrepArgs pa;
         pa.w = w;
@@ -953,22 +1044,40 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         pa.bqkv = bf.bqkv;
         pa.wglu = bf.wglu;
         pa.bglu = bf.bglu;
-        pa.qkv_blocks = 256;
+        pa.wout = bf.wout;
+        pa.wpw2 = bf.wpw2;
+        pa.split = asplit;
+        pa.qkv_blocks = 192;
         pa.glu_blocks = 128;
-        pa.end[0] = (int)grid_for((int64_t)n_w1, 256, 512);
-        pa.end[1] = pa.end[0] + (int)grid_for((int64_t)n_w2, 256, 512);
+        pa.copy_blocks = 32;
+        pa.end[0] = (int)grid_for((int64_t)n_w1 / 4, 256, 256);
+        pa.end[1] = pa.end[0] + (int)grid_for((int64_t)n_w2 / 8, 256, 256);
         pa.end[2] = pa.end[1] + (w.n_out + 3) / 4;
         pa.end[3] = pa.end[2] + 3 * pa.qkv_blocks;
         pa.end[4] = pa.end[3] + (fuse_glu ? 3 * pa.glu_blocks : 0);
-        pa.end[5] = pa.end[4] + 48;
+        pa.end[5] = pa.end[4] + (presplit ? 6 * pa.copy_blocks : 0);
+        pa.end[6] = pa.end[5] + 48;
         pa.wdw = bf.wdw;
-        PROF(PF_U2C_PREP, 0, 8.0 * (n_w1 + n_w2 + n_wh + 3.0 * 3 * INNER * D + (fuse_glu ? 3.0 * 2 * INNER * D : 0.0)),
-             hipLaunchKernelGGL(u2c_prepare_kernel, dim3((unsigned)pa.end[5]), dim3(256), 0, st, pa));
+        PROF(PF_U2C_PREP, 0, 8.0 * (n_w1 + n_w2 + n_wh + 3.0 * 3 * INNER * D + (fuse_glu ? 3.0 * 2 * INNER * D : 0.0) +
+                                    (presplit ? 6.0 * D * INNER : 0.0)),
+             hipLaunchKernelGGL(u2c_prepare_kernel, dim3((unsigned)pa.end[6]), dim3(256), 0, st, pa));
+        if (attn_bf16)   // the three projection matrices as bf16 pieces for the split attention kernels, one launch
+            PROF(PF_U2C_PREP, 0, 3.0 * (4.0 * NF * DH + PERFORMER_P3_BYTES),
+                 performer_p3(st, w.layer[0].proj, w.layer[1].proj, w.layer[2].proj, bf.p3));
     }
+    // with B_split the GEMM reads ONLY the split copy: both pointers name the same packed matrix
+    auto set_b = [&](gemm::Args& g, const float* packed, int a_is_split) {
+        g.math = lin_math;
+        if (presplit) {
+            g.B = packed;
+            g.B_split = packed;
+            g.A_split = a_is_split;
+        }
+    };
     // ---- prenet: conv k3 -> GroupNorm(4) -> LeakyReLU -> conv k3 ----
     {
         gemm::Args g = gemm::make(in.units, w.n_unit, bf.w1, 3 * w.n_unit, iM, D, 3 * w.n_unit);
-        g.math = lin_math;
+        set_b(g, bf.w1, 0);
         g.Fr = (int)Fr;
         g.Cin = w.n_unit;
         g.zeros = zero_page;
@@ -980,11 +1089,11 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
          hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(4, (unsigned)B), dim3(64 * GN_LANES), 0, st, bf.t1, (int)Fr, bf.gst));
     PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
          hipLaunchKernelGGL(groupnorm_lrelu_kernel, dim3(grid_for(M * (D / 4))), dim3(256), 0, st, bf.t1, bf.gst,
-                            w.prenet_gn_w, w.prenet_gn_b, M, (int)Fr, bf.t2));
+                            w.prenet_gn_w, w.prenet_gn_b, M, (int)Fr, bf.t2, asplit));
     float* x = bf.l[0].x_in;
     {
         gemm::Args g = gemm::make(bf.t2, D, bf.w2, 3 * D, iM, D, 3 * D);
-        g.math = lin_math;
+        set_b(g, bf.w2, asplit);
         g.Fr = (int)Fr;
         g.Cin = D;
         g.zeros = zero_page;
@@ -1002,23 +1111,22 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         LayerBufs& b = bf.l[l];
         // -- x_mid = x_in + to_out(linear_attention(LN(x_in)))
         PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
-             hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, b.x_in, L.norm_w, L.norm_b, M, b.y));
+             hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, b.x_in, L.norm_w, L.norm_b, M, b.y, asplit));
         {
             gemm::Args g = gemm::make(b.y, D, bf.wqkv + (size_t)l * 3 * INNER * D, D, iM, 3 * INNER, D);
-            g.math = lin_math;
+            set_b(g, bf.wqkv + (size_t)l * 3 * INNER * D, asplit);
             EpiSplit3 e{{b.q, b.k, b.v}, bf.bqkv + (size_t)l * 3 * INNER};
             PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * 3 * INNER * D, 4.0 * M * (D + 3 * INNER),
                  (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
         }
-        if (!b.pre && lin_math == DDSP_MATH_SPLIT_BF16 && B * H >= 256) {
+        if (attn_bf16) {
             // inference, split-bf16 products, enough (utterance, head) pairs to fill the chip with one workgroup each:
-            // the LDS-staged bf16 kernels (performer_attn_bf16.hip)
+            // the LDS-staged bf16 kernels (performer_attn_bf16.hip); the output is written as the out-projection's A operand
             void* p3 = (char*)bf.p3 + (size_t)l * PERFORMER_P3_BYTES;
-            PROF(PF_U2C_PREP, 0, 4.0 * NF * DH + PERFORMER_P3_BYTES, performer_p3(st, L.proj, p3));
             PROF(PF_U2C_GEMM_CTX, 4.0 * M8 * NF * DH, 4.0 * M * 2 * INNER,
                  performer_kv_bf16(st, b.k, b.v, p3, (int)B, (int)Fr, b.cx, b.ks));
             PROF(PF_U2C_GEMM_ATTNOUT, 4.0 * M8 * NF * DH, 4.0 * M * 2 * INNER,
-                 performer_q_bf16(st, b.q, p3, b.cx, b.ks, (int)B, (int)Fr, b.attn));
+                 performer_q_bf16(st, b.q, p3, b.cx, b.ks, (int)B, (int)Fr, b.attn, 0, asplit));
         } else if (!b.pre) {
             // inference: fused feature maps + linear attention (performer_attn.hip); q'/k' never reach HBM
             PROF(PF_U2C_GEMM_CTX, 4.0 * M8 * NF * DH, 4.0 * M * 2 * INNER,
@@ -1069,17 +1177,17 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         }
         {
             gemm::Args g = gemm::make(b.attn, INNER, L.out_w, INNER, iM, D, INNER);
-            g.math = lin_math;
+            set_b(g, bf.wout + (size_t)l * D * INNER, attn_bf16 ? asplit : 0);
             gemm::EpiResidual e{b.x_mid, b.x_in, D, L.out_b};
             PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * D * INNER, 4.0 * M * (INNER + 2 * D),
                  (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
         }
         // -- x_out = x_mid + conv_module(x_mid)
         PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
-             hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, b.x_mid, L.cm_ln_w, L.cm_ln_b, M, b.y2));
+             hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, b.x_mid, L.cm_ln_w, L.cm_ln_b, M, b.y2, asplit));
         if (fuse_glu) {
             gemm::Args g = gemm::make(b.y2, D, bf.wglu + (size_t)l * 2 * INNER * D, D, iM, 2 * INNER, D);
-            g.math = lin_math;
+            set_b(g, bf.wglu + (size_t)l * 2 * INNER * D, asplit);
             EpiGlu e{b.glu, bf.bglu + (size_t)l * 2 * INNER};
             DDSP_REQUIRE(ctx, gemm::dma_ok(g) && ((uintptr_t)b.glu % 16) == 0, "unit2ctrl: fused GLU needs aligned activations");
             PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * 2 * INNER * D, 4.0 * M * (D + INNER),
@@ -1100,7 +1208,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
                                 dim3(256), 0, st, b.glu, bf.wdw + (size_t)l * DWK * INNER, L.cm_dw_b, (int)B, (int)Fr, b.dwo, b.pre, 1, INNER));
         {
             gemm::Args g = gemm::make(b.dwo, INNER, L.cm_pw2_w, INNER, iM, D, INNER);
-            g.math = lin_math;
+            set_b(g, bf.wpw2 + (size_t)l * D * INNER, 0);
             gemm::EpiResidual e{b.x_out, b.x_mid, D, L.cm_pw2_b};
             PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * D * INNER, 4.0 * M * (INNER + 2 * D),
                  (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
@@ -1110,10 +1218,10 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
     // ---- LayerNorm -> weight-normed head ----
     PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
          hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, bf.l[2].x_out, w.final_ln_w, w.final_ln_b,
-                            M, bf.y_final));
+                            M, bf.y_final, asplit));
     {
         gemm::Args g = gemm::make(bf.y_final, D, bf.wh, D, iM, w.n_out, D);
-        g.math = lin_math;
+        set_b(g, bf.wh, asplit);
         gemm::EpiStore e{ctrl, w.n_out, w.head_b, 1, 0, 0};
         PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * w.n_out * D, 4.0 * M * (D + w.n_out),
              (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));

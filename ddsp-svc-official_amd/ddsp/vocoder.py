@@ -200,13 +200,13 @@ class CombSub(_SynthBase):
         na, nh, nn_ = self.n_mags
         c2 = ctrl.reshape(rows, -1)
         ir_ap = ctx.fir_from_ctrl(FIR_ALLPASS, c2, 0, na, rows, sr)
-        h1, _ = ctx.ltv_fir(ps["comb"], ir_ap, B, Fr, hop, math=ctx.math)
+        h1, _ = ctx.ltv_fir(ps["comb"], ir_ap, B, Fr, hop, math=ctx.fir_math)
         ir_h = ctx.fir_from_ctrl(FIR_DYNAMIC, c2, na, nh, rows, sr, f0_frames)
-        harmonic, _ = ctx.ltv_fir(h1, ir_h, B, Fr, hop, math=ctx.math)
+        harmonic, _ = ctx.ltv_fir(h1, ir_h, B, Fr, hop, math=ctx.fir_math)
         ir_n = ctx.fir_from_ctrl(FIR_STATIC, c2, na + nh, nn_, rows, sr)
         nz, exc, seed = nargs
         noise_out, signal = ctx.ltv_fir(nz, ir_n, B, Fr, hop, excitation=exc, noise_seed=seed, add_in=harmonic,
-                                        math=ctx.math)
+                                        math=ctx.fir_math)
         return (signal, harmonic, noise_out), (ps["comb"], h1, ir_ap, ir_h, ir_n)
 
     def _train_backward(self, ctx, ctrl, saved, f0_frames, nargs, d_outs):
@@ -235,13 +235,13 @@ class CombSub(_SynthBase):
         na, nh, nn_ = self.n_mags
         c2 = ctrl.reshape(rows, -1)
         ir = ctx.fir_from_ctrl(FIR_ALLPASS, c2, 0, na, rows, sr)
-        h, _ = ctx.ltv_fir(comb, ir, B, Fr, hop, math=ctx.math)
+        h, _ = ctx.ltv_fir(comb, ir, B, Fr, hop, math=ctx.fir_math)
         ir = ctx.fir_from_ctrl(FIR_DYNAMIC, c2, na, nh, rows, sr, f0_frames)
-        harmonic, _ = ctx.ltv_fir(h, ir, B, Fr, hop, math=ctx.math)
+        harmonic, _ = ctx.ltv_fir(h, ir, B, Fr, hop, math=ctx.fir_math)
         ir = ctx.fir_from_ctrl(FIR_STATIC, c2, na + nh, nn_, rows, sr)
         nz, exc, seed = self._noise_args(noise, noise_seed)
         noise_out, signal = ctx.ltv_fir(nz, ir, B, Fr, hop, excitation=exc, noise_seed=seed, add_in=harmonic,
-                                        math=ctx.math)
+                                        math=ctx.fir_math)
         return signal, harmonic, noise_out
 
     def forward(self, units_frames, f0_frames, volume_frames, spk_id, spk_mix_dict=None, initial_phase=None,
@@ -283,11 +283,11 @@ class Sins(_SynthBase):
         c2 = ctrl.reshape(rows, -1)
         sinusoids = ctx.sins_bank(c2, 0, nhm, f0_frames, ps["phase"], B, Fr, hop, sr)
         ir_ap = ctx.fir_from_ctrl(FIR_ALLPASS, c2, nhm, na, rows, sr)
-        harmonic, _ = ctx.ltv_fir(sinusoids, ir_ap, B, Fr, hop, math=ctx.math)
+        harmonic, _ = ctx.ltv_fir(sinusoids, ir_ap, B, Fr, hop, math=ctx.fir_math)
         ir_n = ctx.fir_from_ctrl(FIR_STATIC, c2, nhm + na, nn_, rows, sr)
         nz, exc, seed = nargs
         noise_out, signal = ctx.ltv_fir(nz, ir_n, B, Fr, hop, excitation=exc, noise_seed=seed, add_in=harmonic,
-                                        math=ctx.math)
+                                        math=ctx.fir_math)
         return (signal, harmonic, noise_out), (ps["phase"], sinusoids, ir_ap, ir_n)
 
     def _train_backward(self, ctx, ctrl, saved, f0_frames, nargs, d_outs):
@@ -315,11 +315,11 @@ class Sins(_SynthBase):
         c2 = ctrl.reshape(rows, -1)
         sinusoids = ctx.sins_bank(c2, 0, nhm, f0_frames, phase, B, Fr, hop, sr)
         ir = ctx.fir_from_ctrl(FIR_ALLPASS, c2, nhm, na, rows, sr)
-        harmonic, _ = ctx.ltv_fir(sinusoids, ir, B, Fr, hop, math=ctx.math)
+        harmonic, _ = ctx.ltv_fir(sinusoids, ir, B, Fr, hop, math=ctx.fir_math)
         ir = ctx.fir_from_ctrl(FIR_STATIC, c2, nhm + na, nn_, rows, sr)
         nz, exc, seed = self._noise_args(noise, noise_seed)
         noise_out, signal = ctx.ltv_fir(nz, ir, B, Fr, hop, excitation=exc, noise_seed=seed, add_in=harmonic,
-                                        math=ctx.math)
+                                        math=ctx.fir_math)
         return signal, harmonic, noise_out
 
     def forward(self, units_frames, f0_frames, volume_frames, spk_id, spk_mix_dict=None, initial_phase=None,

@@ -179,6 +179,11 @@ class Context:
     def math(self):
         return self.lib.ddsp_ctx_get_math(self.handle)
 
+    @property
+    def fir_math(self):
+        """The `math` argument the model forwards pass to `ddsp_ltv_fir` for this context's mode."""
+        return FIR_FP32 if self.math == MATH_FP32 else FIR_SPLIT_BF16
+
     def set_math(self, math):
         """MATH_SPLIT_BF16 (default) or MATH_FP32: `ddsp_ctx_set_math`; the model forwards pass the same value to
         `ddsp_ltv_fir`."""

@@ -406,3 +406,26 @@ def test_speaker_id_out_of_range_is_reported(dev, lib_path):
     torch.cuda.synchronize()
     with pytest.raises(ValueError, match="spk_id"):
         sig.square().mean().backward()
+
+
+def test_presplit_operands_give_the_same_bits(dev, lib_path):
+    """Round 2: at large batches the producers write the GEMM A operands as bf16 hi/lo groups and the preparation launch
+    the weights, so the split-bf16 GEMM loops split nothing.  The rounding is the same as the in-kernel split (mode 4 of
+    ddsp_ctx_set_math keeps that path as a measurement aid), so the control matrix must be IDENTICAL bit for bit."""
+    import hipddsp
+    for name, B, Fr in (("CombSub", 64, 172), ("CombSubFast", 48, 172), ("Sins", 33, 250)):
+        model, cfg = synthetic.build_model(name, seed=21, device=dev)
+        inp = {k: v.to(dev) for k, v in synthetic.make_inputs(31, B, Fr, with_noise=False).items()}
+        c = hipddsp.context_for(dev)
+        ps = c.phase_scan(inp["f0"], 512, 44100)
+        outs = {}
+        try:
+            for mode in (4, hipddsp.MATH_SPLIT_BF16):
+                c.set_math(mode)
+                with torch.no_grad():
+                    outs[mode] = model.unit2ctrl.forward_flat(inp["units"], inp["f0"], ps["phase_frames"], inp["volume"],
+                                                              inp["spk_id"], None)
+        finally:
+            c.set_math(hipddsp.MATH_SPLIT_BF16)
+        assert torch.equal(outs[4], outs[hipddsp.MATH_SPLIT_BF16]), name
+        assert torch.isfinite(outs[4]).all()
