@@ -223,10 +223,11 @@ def main():
         crit = RSSLoss(256, 2048, 4, device=dev)
         sg = torch.Generator().manual_seed(1234)      # the same n_fft draws on every rank
         gather = None
+        bucket = training.GradBucket(model.parameters())   # every .grad a view of one flat buffer: one all_reduce per step
 
         def step(i):
             scales = [int(v) for v in torch.randint(256, 2048, (4,), generator=sg)]
-            return training.train_step(model, opt, crit, inp, world=world, scales=scales)
+            return training.train_step(model, opt, crit, inp, world=world, scales=scales, bucket=bucket)
     else:
         Bt = B_PER_GPU
 

@@ -62,3 +62,55 @@ class AudioGather:
         if self.stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.stream)
         return self.last
+
+
+class RaggedPlan:
+    """Utterances of different lengths over the ranks (sort by length, pad to frame multiples, gather with
+    counts).  An utterance cannot be padded INSIDE the network (GroupNorm statistics and the linear-attention sums run
+    over all its frames), so every utterance is rendered at its own length; what is padded is the exchange: each rank
+    packs its rendered utterances back to back into one flat buffer of `slot` samples (the largest rank total, the same
+    on every rank because the plan is a pure function of the lengths), one `all_gather_into_tensor` moves the slots, and
+    `unpack` cuts the gathered buffer by the counts into the original order.
+    Assignment: utterances sorted by length (longest first) are dealt to the rank with the least work so far."""
+
+    def __init__(self, n_frames, world, hop=512):
+        self.n_frames = [int(n) for n in n_frames]
+        self.world, self.hop = world, hop
+        order = sorted(range(len(self.n_frames)), key=lambda i: (-self.n_frames[i], i))
+        load = [0] * world
+        self.assign = [[] for _ in range(world)]
+        for i in order:
+            r = min(range(world), key=lambda k: (load[k], k))
+            self.assign[r].append(i)
+            load[r] += self.n_frames[i]
+        self.counts = [[self.n_frames[i] * hop for i in a] for a in self.assign]     # samples per utterance, per rank
+        self.slot = max(1, max(sum(c) for c in self.counts))
+
+    def local(self, rank):
+        """Indices (into the caller's list) of the utterances `rank` renders, in packing order."""
+        return list(self.assign[rank])
+
+    def pack(self, rank, rendered, device="cpu"):
+        """rendered: this rank's (T_i,) audio tensors in `local(rank)` order -> (slot,) flat buffer (zero tail)."""
+        flat = torch.zeros(self.slot, device=device, dtype=torch.float32)
+        off = 0
+        for a, n in zip(rendered, self.counts[rank]):
+            flat[off:off + n] = a.reshape(-1)
+            off += n
+        return flat
+
+    def gather(self, flat, group=None):
+        import torch.distributed as dist
+        out = torch.empty(self.world * self.slot, device=flat.device, dtype=torch.float32)
+        dist.all_gather_into_tensor(out, flat.contiguous(), group=group)
+        return out
+
+    def unpack(self, gathered):
+        """(world * slot,) -> list of (T_i,) tensors in the ORIGINAL utterance order."""
+        out = [None] * len(self.n_frames)
+        for r in range(self.world):
+            off = r * self.slot
+            for i, n in zip(self.assign[r], self.counts[r]):
+                out[i] = gathered[off:off + n]
+                off += n
+        return out

@@ -62,16 +62,52 @@ def allreduce_gradients(params, world, group=None):
         off += n
 
 
-def train_step(model, optimizer, loss_fn, batch, world=1, scales=None):
+class GradBucket:
+    """All gradients of a model in ONE flat fp32 buffer: every `p.grad` is a view into it, so the data-parallel exchange
+    is a single collective on memory that already holds the gradients (no `cat` before, no `copy_` after - 14 MB each
+    way per step otherwise).  autograd accumulates into an existing `.grad` in place, so the views survive a backward
+    pass; `zero()` replaces `optimizer.zero_grad()` (whose default, set_to_none, would drop the views)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        ref = self.params[0]
+        self.flat = torch.zeros(n, device=ref.device, dtype=torch.float32)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def allreduce(self, world, group=None):
+        """Mean over the ranks, one all_reduce (RCCL over xGMI on GPUs)."""
+        if world <= 1:
+            return
+        import torch.distributed as dist
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        self.flat /= world
+
+
+def train_step(model, optimizer, loss_fn, batch, world=1, scales=None, bucket=None):
     """One step of `solver.train` (`solver.py:110-114`): zero_grad -> forward(infer=False) -> loss -> backward -> step.
-    `scales` pins the loss's n_fft draw (ranks of a data-parallel job must share it)."""
-    optimizer.zero_grad()
+    `scales` pins the loss's n_fft draw (ranks of a data-parallel job must share it; both terms of the loss
+    are batch means, `ddsp/loss.py:20-22`, so with equal shards the mean of the rank losses is the global loss and the
+    mean of the rank gradients its gradient).  `bucket`: a GradBucket over the model's parameters (one flat collective)."""
+    if bucket is not None:
+        bucket.zero()
+    else:
+        optimizer.zero_grad()
     signal, _, _ = model(batch["units"].float(), batch["f0"], batch["volume"], batch["spk_id"], infer=False,
                          **({"noise": batch["noise"]} if "noise" in batch else {}))
     if scales is not None:
         loss_fn.set_scales(scales)
     loss = loss_fn(signal, batch["audio"])
     loss.backward()
-    allreduce_gradients(list(model.parameters()), world)
+    if bucket is not None:
+        bucket.allreduce(world)
+    else:
+        allreduce_gradients(list(model.parameters()), world)
     optimizer.step()
     return loss.detach()

@@ -429,3 +429,30 @@ def test_presplit_operands_give_the_same_bits(dev, lib_path):
             c.set_math(hipddsp.MATH_SPLIT_BF16)
         assert torch.equal(outs[4], outs[hipddsp.MATH_SPLIT_BF16]), name
         assert torch.isfinite(outs[4]).all()
+
+
+@pytest.mark.parametrize("name,Fr", [("CombSub", 2600), ("Sins", 2600), ("CombSubFast", 2600), ("CombSub", 10000)])
+def test_long_utterance_against_oracle(dev, lib_path, name, Fr):
+    """Validation renders whole files at batch 1 (solver.py:9-82): 30 s (2 600 frames) for all three models and 116 s
+    (10 000 frames) for CombSub against the CPU oracle.  GroupNorm statistics, the Performer key sums, the frame prefix of
+    the phase scan and the FIR's marching runs all grow with the number of frames."""
+    import os
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    model, cfg = synthetic.build_model(name, seed=23)
+    sd = model.state_dict()
+    inp = synthetic.make_inputs(600 + Fr, 1, Fr)
+    with torch.no_grad():
+        sig_o, ph_o, (hm_o, nz_o), _ = OS.FORWARD[cfg["type"]](sd, cfg, inp["units"], inp["f0"], inp["volume"], inp["spk_id"],
+                                                               infer=True, noise=inp["noise"])
+    model = model.to(dev).eval()
+    d = _to(inp, dev)
+    with torch.no_grad():
+        sig, ph, (hm, nz) = model(d["units"], d["f0"], d["volume"], d["spk_id"], infer=True, noise=d["noise"])
+    assert sig.shape == (1, Fr * 512)
+    assert rms(sig.cpu() - sig_o) < GATE, (name, Fr, rms(sig.cpu() - sig_o), rms(sig_o))
+    assert rms(hm.cpu() - hm_o) < GATE and rms(nz.cpu() - nz_o) < GATE
+    # the phase keeps its precision over the whole file (fp64 running sum): compare the wrapped difference
+    dph = (ph.cpu() - ph_o).double() / (2 * np.pi)
+    dph = dph - torch.round(dph)
+    assert float(dph.abs().max()) < 2e-5, float(dph.abs().max())
+    assert rms(sig_o) > 1e-3

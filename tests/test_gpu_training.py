@@ -256,3 +256,30 @@ def test_train_step_bench_batch_against_autograd(dev, lib_path):
     errs = sorted(((_rel(p.grad.cpu(), params[n].grad), n) for n, p in model.named_parameters()), reverse=True)
     assert errs[0][0] < 1e-2, errs[:5]
     assert sum(e for e, _ in errs) / len(errs) < 5e-3, errs[:5]
+
+
+def test_grad_bucket_train_step_equals_plain(dev, lib_path):
+    """`training.GradBucket`: every .grad is a view of one flat buffer (one data-parallel collective, no cat / copy_).  A step
+    through the bucket gives the same parameters as the plain step, and the views survive backward passes."""
+    import training
+    from ddsp.loss import RSSLoss
+    B, Fr = 3, 40
+    inp = {k: v.to(dev) for k, v in synthetic.make_inputs(91, B, Fr).items()}
+    inp["audio"] = (0.1 * torch.randn(B, Fr * 512, generator=torch.Generator().manual_seed(2))).to(dev)
+    outs = []
+    for use_bucket in (False, True):
+        model, cfg = synthetic.build_model("CombSub", seed=29, device=dev)
+        model.train()
+        opt = training.AdamW(model.parameters(), lr=5e-4, weight_decay=0.0)
+        crit = RSSLoss(256, 2048, 4, device=dev)
+        bucket = training.GradBucket(model.parameters()) if use_bucket else None
+        for step in range(2):
+            loss = training.train_step(model, opt, crit, inp, scales=[300, 777, 1531, 2047], bucket=bucket)
+        if use_bucket:
+            lo, hi = bucket.flat.data_ptr(), bucket.flat.data_ptr() + 4 * bucket.flat.numel()
+            assert all(lo <= p.grad.data_ptr() < hi for p in bucket.params)
+            assert float(bucket.flat.abs().sum()) > 0
+        outs.append((float(loss), [p.detach().clone() for p in model.parameters()]))
+    assert outs[0][0] == outs[1][0]
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
