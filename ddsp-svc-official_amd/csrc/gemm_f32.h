@@ -753,8 +753,9 @@ inline void launch(hipStream_t st, const Args& g, int batch, const Epi& epi) {
             return;
         }
     }
-    if (g.B_split || g.A_split) {
-        // pre-split operands exist only for the DMA kernel: the caller's size predicate and this function disagree
+    if ((g.B_split && g.B_split == g.B) || g.A_split) {
+        // operands that exist ONLY pre-split can be read by the DMA kernel alone (a caller that also has the fp32 matrix passes
+        // it as B and lands here legitimately): the caller's size predicate and this function disagree
         fprintf(stderr, "libddsp_amd: internal error: pre-split GEMM operands on the register-staged path (M=%d N=%d K=%d)\n",
                 g.M, g.N, g.K);
         abort();
