@@ -1,0 +1,127 @@
+// SURVEY 8(f) rank 3 - device-side sample-rate conversion: the windowed-sinc polyphase resampler the reference takes
+// from torchaudio (`Resample(orig, new, lowpass_filter_width=128)`: gui.py:399-404 between the model's and the audio
+// device's rate, enhancer.py:50-53,69-73 around the adaptive-key trick).  torchaudio is a third-party package that is
+// not in the image: the algorithm below is its published one (torchaudio.functional.resample, `sinc_interp_hann`,
+// rolloff 0.99), PARITY UNPINNED at that boundary; tests hold the kernels to an fp64 evaluation of the same formulas.
+//   orig, new reduced by their gcd; base = min(orig, new) * rolloff; width = ceil(lowpass_width * orig / base);
+//   tap[p][k] = sinc(pi t) * cos^2(pi t / (2 lowpass_width)) * base / orig,
+//       t = clamp((-p / new + (k - width) / orig) * base, -lowpass_width, lowpass_width),   p < new, k < 2 width + orig;
+//   out[l * new + p] = sum_k x[l * orig + k - width] * tap[p][k]   (x zero outside [0, T)),  T_out = ceil(new * T / orig).
+// The taps are evaluated in fp64 and rounded to fp32 once (torchaudio computes them in fp64 too when no dtype is given);
+// the table is cached in the context (one per rate pair).  The convolution is a streaming kernel: one thread per output
+// sample, its 2 width + orig input samples are contiguous and shared with the neighbouring phases through L1.
+#include "common.h"
+
+#include <math.h>
+
+namespace {
+
+__global__ void __launch_bounds__(256) resample_taps_kernel(float* __restrict__ taps, int orig, int nw, int width, int K,
+                                                            double base, double lpw) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)nw * K) return;
+    const int p = (int)(i / K), k = (int)(i - (int64_t)p * K);
+    double t = (-(double)p / (double)nw + (double)(k - width) / (double)orig) * base;
+    t = t < -lpw ? -lpw : (t > lpw ? lpw : t);
+    const double c = cos(t * M_PI / lpw / 2.0);
+    const double tp = t * M_PI;
+    const double s = tp == 0.0 ? 1.0 : sin(tp) / tp;
+    taps[i] = (float)(s * c * c * (base / (double)orig));
+}
+
+__global__ void __launch_bounds__(256) resample_kernel(const float* __restrict__ x, const float* __restrict__ taps,
+                                                       int64_t T, int64_t T_out, int orig, int nw, int width, int K,
+                                                       int64_t total, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / T_out, o = i - b * T_out;
+        const int64_t l = o / nw;
+        const int p = (int)(o - l * nw);
+        const float* xr = x + b * T;
+        const float* tp = taps + (int64_t)p * K;
+        const int64_t first = l * orig - width;
+        int k0 = first < 0 ? (int)(-first) : 0;
+        int k1 = first + K > T ? (int)(T - first) : K;
+        // four partial sums (the order of a long fp32 sum matters at the 1e-7 level; a blocked sum is closer to the exact
+        // value than a running one)
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int k = k0;
+        for (; k + 3 < k1; k += 4) {
+            a0 = fmaf(xr[first + k], tp[k], a0);
+            a1 = fmaf(xr[first + k + 1], tp[k + 1], a1);
+            a2 = fmaf(xr[first + k + 2], tp[k + 2], a2);
+            a3 = fmaf(xr[first + k + 3], tp[k + 3], a3);
+        }
+        for (; k < k1; ++k) a0 = fmaf(xr[first + k], tp[k], a0);
+        out[i] = (a0 + a1) + (a2 + a3);
+    }
+}
+
+int gcd_int(int a, int b) {
+    while (b) {
+        const int t = a % b;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+
+}  // namespace
+
+constexpr int TAB_RESAMPLE = 100;   // table kinds 100.. (tables.hip keeps 0..): key (orig/g) * 2^16 + (new/g), lowpass width
+
+extern "C" int64_t ddsp_resample_length(int64_t T, int orig_freq, int new_freq) {
+    if (T < 0 || orig_freq < 1 || new_freq < 1) return -1;
+    const int g = gcd_int(orig_freq, new_freq);
+    const int64_t o = orig_freq / g, n = new_freq / g;
+    return (n * T + o - 1) / o;
+}
+
+extern "C" int ddsp_resample(ddsp_ctx* ctx, void* stream, const float* x, int64_t B, int64_t T, int orig_freq, int new_freq,
+                             int lowpass_filter_width, float* out) {
+    DDSP_REQUIRE(ctx, ctx && x && out, "ddsp_resample: null argument");
+    DDSP_REQUIRE(ctx, B >= 0 && T >= 1 && orig_freq >= 1 && new_freq >= 1 && lowpass_filter_width >= 1 &&
+                          lowpass_filter_width <= 4096,
+                 "ddsp_resample: bad argument");
+    if (B == 0) return DDSP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    const int g = gcd_int(orig_freq, new_freq);
+    const int orig = orig_freq / g, nw = new_freq / g;
+    DDSP_REQUIRE(ctx, orig < 65536 && nw < 65536, "ddsp_resample: rate ratio too fine (reduced rates must be < 65536)");
+    const double rolloff = 0.99;
+    const double base = (double)(orig < nw ? orig : nw) * rolloff;
+    const int width = (int)ceil((double)lowpass_filter_width * (double)orig / base);
+    const int K = 2 * width + orig;
+    DDSP_REQUIRE(ctx, (int64_t)nw * K < (1 << 28), "ddsp_resample: tap table too large");
+    // cached table: kind TAB_RESAMPLE, key (orig << 16 | new, lowpass width)
+    float* taps = nullptr;
+    const int key0 = (orig << 16) | nw;
+    for (int i = 0; i < ctx->n_tables; ++i)
+        if (ctx->tables[i].kind == TAB_RESAMPLE && ctx->tables[i].n0 == key0 && ctx->tables[i].n1 == lowpass_filter_width)
+            taps = ctx->tables[i].dev;
+    if (!taps) {
+        if (ctx->n_tables >= 64) return ddsp_fail(ctx, DDSP_ERR_OOM, "table cache full", "");
+        const size_t bytes = (size_t)nw * K * sizeof(float);
+        hipError_t e = hipMalloc((void**)&taps, bytes);
+        if (e != hipSuccess) return ddsp_fail(ctx, DDSP_ERR_OOM, "resample taps hipMalloc", hipGetErrorString(e));
+        hipLaunchKernelGGL(resample_taps_kernel, dim3((unsigned)(((int64_t)nw * K + 255) / 256)), dim3(256), 0, st, taps, orig,
+                           nw, width, K, base, (double)lowpass_filter_width);
+        DDSP_LAUNCH_CHECK(ctx);
+        ddsp_table& t = ctx->tables[ctx->n_tables++];
+        t.kind = TAB_RESAMPLE;
+        t.n0 = key0;
+        t.n1 = lowpass_filter_width;
+        t.dev = taps;
+        t.bytes = bytes;
+    }
+    const int64_t T_out = ((int64_t)nw * T + orig - 1) / orig;
+    const int64_t total = B * T_out;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    ddsp_prof_begin(ctx, st, PF_OTHER);
+    hipLaunchKernelGGL(resample_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, taps, T, T_out, orig, nw, width, K, total,
+                       out);
+    ddsp_prof_end(ctx, st, 2.0 * total * K, 4.0 * (B * T + total));
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}

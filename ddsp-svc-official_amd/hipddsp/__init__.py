@@ -74,6 +74,8 @@ SIGNATURES = {
     "ddsp_phase_vocoder": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
     "ddsp_volume_extract": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp]),
     "ddsp_align_units": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp]),
+    "ddsp_resample_length": (_i64, [_i64, _int, _int]),
+    "ddsp_resample": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _int, _vp]),
     "ddsp_adamw_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64]),
     "ddsp_adamw_step_multi": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _i64]),
     "ddsp_gemm_f32": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _i64, _int, _vp, _vp, _i64, _int, _int, _int, _int, _int]),
@@ -341,6 +343,20 @@ class Context:
             return out
         self.call("ddsp_align_units", _ptr(units), B, Lu, C, int(n_frames), float(ratio), _ptr(out))
         return out
+
+    # -- sample-rate conversion ---------------------------------------------
+    def resample(self, audio, orig_freq, new_freq, lowpass_filter_width=6):
+        """audio (B,T) or (T,) -> (B, ceil(T*new/orig)): windowed-sinc polyphase (torchaudio.transforms.Resample's algorithm)."""
+        flat = audio.dim() == 1
+        x = (audio.reshape(1, -1) if flat else audio).contiguous().float()
+        B, T = x.shape
+        T_out = self.lib.ddsp_resample_length(T, int(orig_freq), int(new_freq))
+        if T_out < 0:
+            raise ValueError("resample: bad rates")
+        out = torch.empty(B, T_out, device=x.device, dtype=torch.float32)
+        if B and T:
+            self.call("ddsp_resample", _ptr(x), B, T, int(orig_freq), int(new_freq), int(lowpass_filter_width), _ptr(out))
+        return out[0] if flat else out
 
     # -- a15 optimiser -------------------------------------------------------------------------
     def adamw_step(self, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):

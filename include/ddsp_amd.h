@@ -234,6 +234,15 @@ int ddsp_volume_extract(ddsp_ctx* ctx, void* stream, const float* audio, int64_t
 int ddsp_align_units(ddsp_ctx* ctx, void* stream, const float* units, int64_t B, int64_t Lu, int64_t C,
                      int64_t n_frames, float ratio, float* out);
 
+/* ---- sample-rate conversion ------------------------------------------------------ */
+/* replaces `torchaudio.transforms.Resample(orig_freq, new_freq, lowpass_filter_width)` as the reference uses it (gui.py:399-404,
+ * enhancer.py:50-53,69-73; windowed-sinc polyphase, Hann window, rolloff 0.99 - torchaudio's published algorithm; the package
+ * is not in the image, so parity at that boundary is unpinned): x (B,T) -> out (B, ddsp_resample_length(T, orig, new)).
+ * The tap table of a rate pair is built on first use and cached in the context. */
+int64_t ddsp_resample_length(int64_t T, int orig_freq, int new_freq);
+int ddsp_resample(ddsp_ctx* ctx, void* stream, const float* x, int64_t B, int64_t T, int orig_freq, int new_freq,
+                  int lowpass_filter_width, float* out);
+
 /* ---- a15: optimiser step --------------------------------------------------------------------- */
 /* replaces one parameter's update of torch.optim.AdamW (train.py:41, solver.py:114): decoupled weight decay,
  * bias-corrected moments, `step` counted from 1.  All buffers hold n fp32 values. */
