@@ -8,6 +8,9 @@
 //   A_MODE = A_CONV3: A is X (rows x Cin); k = tap*Cin + c and A(m,k) = X[m + tap - 1][c] when frame
 //                 (m % Fr) + tap - 1 stays inside [0, Fr), else 0: a zero-padded k=3 Conv1d over the
 //                 frame axis without materialising im2col.
+//   A_MODE = A_CONVK: the same with `ktaps` taps `dil` frames apart, centred ("same" padding: tap t reads frame
+//                 m + (t - (ktaps-1)/2)*dil), and an optional leaky-ReLU (slope `in_slope`) applied to A as it is loaded: the
+//                 dilated convolutions of the NSF-HiFiGAN generator (register-staged kernel only).
 //   A_MODE = A_FRAMES: rows are non-overlapping length-lda frames of B signals: row m lives at
 //                 A[(m / Fr)*sA_hi + (m % Fr)*lda] (Fr frames per signal, signals sA_hi apart) - the STFT framing of
 //                 the spectral loss without a copy.
@@ -30,7 +33,7 @@
 
 namespace gemm {
 
-enum { A_PLAIN = 0, A_CONV3 = 1, A_FRAMES = 2 };
+enum { A_PLAIN = 0, A_CONV3 = 1, A_FRAMES = 2, A_CONVK = 3 };
 
 struct Args {
     const float* A;
@@ -40,8 +43,10 @@ struct Args {
     // batching over blockIdx.z: z -> (z / zdiv, z % zdiv)
     int zdiv;
     int64_t sA_hi, sA_lo, sB_hi, sB_lo;
-    // conv3 mode
+    // conv3 / convK mode
     int Fr, Cin;
+    int ktaps, dil;       // A_CONVK
+    float in_slope;       // A_CONVK: leaky-ReLU slope applied to A on load (1 = none)
     const float* zeros;   // >= Cin + 32 zero floats (DMA kernel, conv3 mode: source of the taps that fall off an utterance)
     // remainder mode of the DMA kernel (sub_from > 0): tile t of this launch is quadrant t & 3 of the PARENT tiling's tile
     // sub_from + t / 4, the parent tiles being twice as large in both directions and parent_tn of them per row
@@ -153,6 +158,17 @@ __global__ void __launch_bounds__(64 * NW) kernel(Args g, Epi epi) {
                         const int tap = k / g.Cin, c = k - tap * g.Cin;
                         const int f = m % g.Fr + tap - 1;
                         if (f >= 0 && f < g.Fr) v = *(const f32x4_u*)(A + (int64_t)(m + tap - 1) * g.lda + c);
+                    }
+                } else if (A_MODE == A_CONVK) {
+                    if (m < g.M && k < g.K) {
+                        const int tap = k / g.Cin, c = k - tap * g.Cin;
+                        const int off = (tap - (g.ktaps - 1) / 2) * g.dil;
+                        const int f = m % g.Fr + off;
+                        if (f >= 0 && f < g.Fr) {
+                            v = *(const f32x4_u*)(A + (int64_t)(m + off) * g.lda + c);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * g.in_slope;
+                        }
                     }
                 } else if (a_full) {
                     v = *(const f32x4_u*)(arow(m) + k);
@@ -779,6 +795,9 @@ inline Args make(const float* A, int64_t lda, const float* B, int64_t ldb, int M
     g.sA_hi = g.sA_lo = g.sB_hi = g.sB_lo = 0;
     g.Fr = 1;
     g.Cin = 4;
+    g.ktaps = 3;
+    g.dil = 1;
+    g.in_slope = 1.f;
     g.zeros = nullptr;
     g.sub_from = 0;
     g.parent_tn = 0;

@@ -1,0 +1,259 @@
+// SURVEY 8(f) rank 1 - the NSF-HiFiGAN post-net of the reference's `Enhancer` (enhancer.py:24-101, nsf_hifigan/models.py:
+// 106-276): harmonic source (SineGen + SourceModuleHnNSF), the generator's convolution stack, and the log-mel front end
+// (nsf_hifigan/nvSTFT.py:65-119).  Batch 1 (the reference calls it with one utterance), activations frame-major (T, C).
+//   * every Conv1d / ConvTranspose1d with more than one input channel is a GEMM on the fp32 matrix pipe with an implicit
+//     im2col loader (gemm_f32.h, A_CONVK: k taps `dil` frames apart, "same" padding, the preceding leaky-ReLU applied while
+//     the operand is loaded; bias and the residual / source addition in the epilogue).  A transposed convolution of stride
+//     u and kernel 2u is the 3-tap case: output frame t*u + r takes inputs t-1, t (r < u/2) or t, t+1 (r >= u/2), so with the
+//     weights re-packed to (u*Cout, 3*Cin) - zeros where a tap does not reach - the GEMM's (T, u*Cout) result IS the
+//     (T*u, Cout) output;
+//   * the source: per harmonic the phase is the running sum of f0*h/sr over samples (fp64; the reference's cumsum with its
+//     wrap-around bookkeeping differs from any other integer-wrapped sum by whole cycles only), frame prefix by a scan over
+//     frames, samples in closed form inside a frame; tanh(Linear(9 -> 1)) fused;
+//   * the 1-channel strided "noise" convolutions, the 1-output-channel post convolution (+ tanh) and the mean over the
+//     residual blocks are small streaming kernels.
+// These kernels are correct-first: fp32 MFMA on the register-staged GEMM kernel, no tuning (the enhancer is the step after
+// the hot path, not part of the benchmarked one).
+#include "gemm_f32.h"
+
+#include <math.h>
+
+namespace {
+
+constexpr int NH = 9;   // harmonics of the source module (harmonic_num = 8, nsf_hifigan/models.py:227-230)
+
+// ---- source -------------------------------------------------------------------------------------------------------------
+// prefix[l][h] = sum over frames l' < l of upp * rad[l'][h] (mod 1), rad = frac(f0 * (h + 1) / sr) (+ rand_ini on frame 0), fp64
+__global__ void __launch_bounds__(64) nsf_frame_prefix_kernel(const float* __restrict__ f0, const float* __restrict__ rand_ini,
+                                                              int L, int upp, float sr, double* __restrict__ prefix) {
+    const int h = threadIdx.x;
+    if (h >= NH) return;
+    double acc = 0.0;
+    for (int l = 0; l < L; ++l) {
+        prefix[(int64_t)l * NH + h] = acc;
+        float rad = fmodf(__fdiv_rn(f0[l] * (float)(h + 1), sr), 1.0f);      // (fn / sampling_rate) % 1 in fp32
+        if (l == 0) rad += rand_ini[h];
+        acc += (double)upp * (double)rad;
+        acc -= floor(acc);
+    }
+}
+
+__global__ void __launch_bounds__(256) nsf_source_kernel(const float* __restrict__ f0, const float* __restrict__ rand_ini,
+                                                         const double* __restrict__ prefix, const float* __restrict__ w,
+                                                         const float* __restrict__ b, int L, int upp, float sr, float amp,
+                                                         float* __restrict__ out) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= (int64_t)L * upp) return;
+    const int l = (int)(n / upp), j = (int)(n - (int64_t)l * upp);
+    float s = b[0];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        float rad = fmodf(__fdiv_rn(f0[l] * (float)(h + 1), sr), 1.0f);
+        if (l == 0) rad += rand_ini[h];
+        double ph = prefix[(int64_t)l * NH + h] + (double)(j + 1) * (double)rad;
+        ph -= floor(ph);
+        const float sine = (float)sin(ph * 6.283185307179586) * amp;
+        s = fmaf(w[h], sine, s);
+    }
+    out[n] = tanhf(s);
+}
+
+// ---- 1-channel strided convolution: out[t][c] = b[c] + sum_j w[c][j] * src[t*s - pad + j] ----------------------------------------
+__global__ void __launch_bounds__(256) nsf_noise_conv_kernel(const float* __restrict__ src, int64_t T_src,
+                                                             const float* __restrict__ w, const float* __restrict__ b,
+                                                             int64_t T_out, int C, int K, int stride, int pad,
+                                                             float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= T_out * C) return;
+    const int64_t t = i / C;
+    const int c = (int)(i - t * C);
+    float acc = b[c];
+    const int64_t first = t * stride - pad;
+    for (int j = 0; j < K; ++j) {
+        const int64_t p = first + j;
+        if (p >= 0 && p < T_src) acc = fmaf(w[c * K + j], src[p], acc);
+    }
+    out[i] = acc;
+}
+
+// ---- post: tanh(conv7(leaky_relu(x, 0.01))) with one output channel ------------------------------------------------------------
+__global__ void __launch_bounds__(256) nsf_post_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ b, int64_t T, int C, int K, float slope,
+                                                       float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    float acc = b[0];
+    for (int j = 0; j < K; ++j) {
+        const int64_t p = t + j - (K - 1) / 2;
+        if (p < 0 || p >= T) continue;
+        const float* xr = x + p * C;
+        for (int c = 0; c < C; ++c) {
+            const float v = xr[c];
+            acc = fmaf(w[j * C + c], v > 0.f ? v : v * slope, acc);
+        }
+    }
+    out[t] = tanhf(acc);
+}
+
+__global__ void __launch_bounds__(256) nsf_mean_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       const float* __restrict__ c, int n_terms, int64_t n,
+                                                       float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float s = a[i];
+        if (n_terms > 1) s += b[i];
+        if (n_terms > 2) s += c[i];
+        out[i] = s / (float)n_terms;
+    }
+}
+
+// ---- log-mel: out[t][m] = log(max(sum_f mel[m][f] * sqrt(re^2 + im^2 + 1e-9), clip)) ------------------------------------------
+__global__ void __launch_bounds__(256) nsf_magnitude_kernel(const float* __restrict__ spec, int64_t rows, int bins, int ld,
+                                                            float* __restrict__ mag, int ldm) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * ldm) return;
+    const int64_t r = i / ldm;
+    const int f = (int)(i - r * ldm);
+    float v = 0.f;
+    if (f < bins) {
+        const float re = spec[r * ld + 2 * f], im = spec[r * ld + 2 * f + 1];
+        v = sqrtf(re * re + im * im + 1e-9f);
+    }
+    mag[i] = v;
+}
+__global__ void __launch_bounds__(256) nsf_logclamp_kernel(float* __restrict__ x, int64_t n, float clip) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] = logf(fmaxf(x[i], clip));
+}
+
+struct EpiAddBias {   // C = acc + bias[n] (+ res): the plain and the residual / source-addition epilogue of the generator's convs
+    float* C;
+    const float* res;
+    int64_t ldc;
+    const float* bias;
+    __device__ __forceinline__ float col(int n) const { return bias ? bias[n] : 0.f; }
+    __device__ __forceinline__ void operator()(int, int m, int n, float v, float cb) const {
+        const int64_t o = (int64_t)m * ldc + n;
+        const float y = v + cb;
+        C[o] = res ? y + res[o] : y;
+    }
+};
+
+}  // namespace
+
+extern "C" int ddsp_conv1d(ddsp_ctx* ctx, void* stream, const float* x, const float* w_packed, const float* bias, int64_t T,
+                           int Cin, int Cout, int ktaps, int dil, float in_slope, const float* residual, float* out) {
+    DDSP_REQUIRE(ctx, ctx && x && w_packed && out, "ddsp_conv1d: null argument");
+    DDSP_REQUIRE(ctx, T >= 1 && T < (1 << 30) && Cin >= 4 && Cin % 4 == 0 && Cout >= 1 && ktaps >= 1 && ktaps % 2 == 1 &&
+                          ktaps <= 63 && dil >= 1 && dil <= 64,
+                 "ddsp_conv1d: bad shape (Cin % 4 == 0, odd tap count)");
+    DDSP_REQUIRE(ctx, x != out, "ddsp_conv1d: in-place convolution is not possible");
+    hipStream_t st = (hipStream_t)stream;
+    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    gemm::Args g = gemm::make(x, Cin, w_packed, (int64_t)ktaps * Cin, (int)T, Cout, ktaps * Cin);
+    g.Fr = (int)T;
+    g.Cin = Cin;
+    g.ktaps = ktaps;
+    g.dil = dil;
+    g.in_slope = in_slope;
+    EpiAddBias e{out, residual, Cout, bias};
+    ddsp_prof_begin(ctx, st, PF_OTHER);
+    if ((int64_t)((T + 127) / 128) * ((Cout + 63) / 64) >= 512)
+        gemm::launch_tile<128, 64, true, true, gemm::A_CONVK, EpiAddBias, 8>(st, g, 1, e);
+    else
+        gemm::launch_tile<64, 64, true, true, gemm::A_CONVK, EpiAddBias, 4>(st, g, 1, e);
+    ddsp_prof_end(ctx, st, 2.0 * T * (double)Cout * ktaps * Cin, 4.0 * T * ((double)Cin + Cout));
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}
+
+extern "C" int ddsp_nsf_source(ddsp_ctx* ctx, void* stream, const float* f0, const float* rand_ini, const float* lin_w,
+                               const float* lin_b, int64_t L, int upp, int sr, float sine_amp, float* out) {
+    DDSP_REQUIRE(ctx, ctx && f0 && rand_ini && lin_w && lin_b && out, "ddsp_nsf_source: null argument");
+    DDSP_REQUIRE(ctx, L >= 1 && L < (1 << 24) && upp >= 1 && upp <= 65536 && sr >= 1, "ddsp_nsf_source: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ddsp_scratch_reserve_bytes(ctx, (size_t)L * NH * sizeof(double) + 4096);
+    if (rc) return rc;
+    ddsp_scratch_reset(ctx);
+    double* prefix = nullptr;
+    if ((rc = ddsp_scratch_get(ctx, (size_t)L * NH * sizeof(double), (void**)&prefix))) return rc;
+    hipLaunchKernelGGL(nsf_frame_prefix_kernel, dim3(1), dim3(64), 0, st, f0, rand_ini, (int)L, upp, (float)sr, prefix);
+    const int64_t n = L * upp;
+    hipLaunchKernelGGL(nsf_source_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f0, rand_ini, prefix, lin_w, lin_b,
+                       (int)L, upp, (float)sr, sine_amp, out);
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}
+
+extern "C" int ddsp_nsf_noise_conv(ddsp_ctx* ctx, void* stream, const float* src, int64_t T_src, const float* w,
+                                   const float* b, int C, int K, int stride, int pad, int64_t T_out, float* out) {
+    DDSP_REQUIRE(ctx, ctx && src && w && b && out, "ddsp_nsf_noise_conv: null argument");
+    DDSP_REQUIRE(ctx, T_src >= 1 && T_out >= 1 && C >= 1 && K >= 1 && stride >= 1 && pad >= 0 && T_out * C < ((int64_t)1 << 40),
+                 "ddsp_nsf_noise_conv: bad shape");
+    DDSP_REQUIRE(ctx, (T_out - 1) * stride - pad < T_src, "ddsp_nsf_noise_conv: output longer than the source allows");
+    hipStream_t st = (hipStream_t)stream;
+    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(nsf_noise_conv_kernel, dim3((unsigned)((T_out * C + 255) / 256)), dim3(256), 0, st, src, T_src, w, b, T_out,
+                       C, K, stride, pad, out);
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}
+
+extern "C" int ddsp_nsf_post(ddsp_ctx* ctx, void* stream, const float* x, const float* w, const float* b, int64_t T, int C, int K,
+                             float slope, float* out) {
+    DDSP_REQUIRE(ctx, ctx && x && w && b && out, "ddsp_nsf_post: null argument");
+    DDSP_REQUIRE(ctx, T >= 1 && C >= 1 && K >= 1 && K % 2 == 1, "ddsp_nsf_post: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(nsf_post_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, x, w, b, T, C, K, slope, out);
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}
+
+extern "C" int ddsp_nsf_mean(ddsp_ctx* ctx, void* stream, const float* a, const float* b, const float* c, int n_terms, int64_t n,
+                             float* out) {
+    DDSP_REQUIRE(ctx, ctx && a && out && n_terms >= 1 && n_terms <= 3 && (n_terms < 2 || b) && (n_terms < 3 || c) && n >= 0,
+                 "ddsp_nsf_mean: bad argument");
+    if (n == 0) return DDSP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(nsf_mean_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, b, c, n_terms, n, out);
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}
+
+extern "C" int ddsp_log_mel(ddsp_ctx* ctx, void* stream, const float* frames, const float* dft_table, const float* mel_basis,
+                            int64_t n_frames, int n_fft, int n_mels, float clip, float* out) {
+    // frames (n_frames, n_fft) already windowed-by-table: dft_table (2*bins_padded, n_fft) rows 2f = w*cos, 2f+1 = -w*sin;
+    // mel_basis (n_mels, bins_padded) zero-padded columns; out (n_frames, n_mels)
+    DDSP_REQUIRE(ctx, ctx && frames && dft_table && mel_basis && out, "ddsp_log_mel: null argument");
+    DDSP_REQUIRE(ctx, n_frames >= 1 && n_frames < (1 << 24) && n_fft >= 4 && n_fft % 4 == 0 && n_mels >= 1,
+                 "ddsp_log_mel: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    const int bins = n_fft / 2 + 1, ldm = (bins + 3) & ~3, lds = 2 * ldm;
+    int rc = ddsp_scratch_reserve_bytes(ctx, (size_t)n_frames * (lds + ldm) * sizeof(float) + 8192);
+    if (rc) return rc;
+    ddsp_scratch_reset(ctx);
+    float *spec = nullptr, *mag = nullptr;
+    if ((rc = ddsp_scratch_get(ctx, (size_t)n_frames * lds * sizeof(float), (void**)&spec))) return rc;
+    if ((rc = ddsp_scratch_get(ctx, (size_t)n_frames * ldm * sizeof(float), (void**)&mag))) return rc;
+    {
+        gemm::Args g = gemm::make(frames, n_fft, dft_table, n_fft, (int)n_frames, lds, n_fft);
+        gemm::EpiStore e{spec, lds, nullptr, 1, 0, 0};
+        gemm::launch_tile<64, 64, true, true, gemm::A_PLAIN, gemm::EpiStore, 4>(st, g, 1, e);
+    }
+    hipLaunchKernelGGL(nsf_magnitude_kernel, dim3((unsigned)((n_frames * ldm + 255) / 256)), dim3(256), 0, st, spec, n_frames, bins,
+                       lds, mag, ldm);
+    {
+        gemm::Args g = gemm::make(mag, ldm, mel_basis, ldm, (int)n_frames, n_mels, ldm);
+        gemm::EpiStore e{out, n_mels, nullptr, 1, 0, 0};
+        gemm::launch_tile<64, 64, true, true, gemm::A_PLAIN, gemm::EpiStore, 4>(st, g, 1, e);
+    }
+    hipLaunchKernelGGL(nsf_logclamp_kernel, dim3((unsigned)((n_frames * n_mels + 255) / 256)), dim3(256), 0, st, out,
+                       n_frames * n_mels, clip);
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}

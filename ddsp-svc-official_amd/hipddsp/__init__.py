@@ -76,6 +76,12 @@ SIGNATURES = {
     "ddsp_align_units": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp]),
     "ddsp_resample_length": (_i64, [_i64, _int, _int]),
     "ddsp_resample": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _int, _vp]),
+    "ddsp_conv1d": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _vp, _vp]),
+    "ddsp_nsf_source": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _f32, _vp]),
+    "ddsp_nsf_noise_conv": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _int, _int, _int, _int, _i64, _vp]),
+    "ddsp_nsf_post": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _f32, _vp]),
+    "ddsp_nsf_mean": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]),
+    "ddsp_log_mel": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _f32, _vp]),
     "ddsp_adamw_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64]),
     "ddsp_adamw_step_multi": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _i64]),
     "ddsp_gemm_f32": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _i64, _int, _vp, _vp, _i64, _int, _int, _int, _int, _int]),
@@ -357,6 +363,53 @@ class Context:
         if B and T:
             self.call("ddsp_resample", _ptr(x), B, T, int(orig_freq), int(new_freq), int(lowpass_filter_width), _ptr(out))
         return out[0] if flat else out
+
+    # -- NSF-HiFiGAN post-net building blocks --------------------------------
+    def conv1d(self, x, w_packed, bias, ktaps, dil, in_slope, residual=None):
+        """x (T,Cin), w_packed (Cout, ktaps*Cin) -> (T,Cout) = conv_same(leaky_relu(x, in_slope)) + bias (+ residual)."""
+        T, Cin = x.shape
+        Cout = w_packed.shape[0]
+        if w_packed.shape[1] != ktaps * Cin:
+            raise ValueError("conv1d: packed weight does not match (ktaps, Cin)")
+        out = torch.empty(T, Cout, device=x.device, dtype=torch.float32)
+        self.call("ddsp_conv1d", _ptr(x), _ptr(w_packed), _ptr(bias), T, Cin, Cout, int(ktaps), int(dil), float(in_slope),
+                  _ptr(residual), _ptr(out))
+        return out
+
+    def nsf_source(self, f0, rand_ini, lin_w, lin_b, upp, sr, sine_amp=0.1):
+        L = f0.numel()
+        out = torch.empty(L * int(upp), device=f0.device, dtype=torch.float32)
+        self.call("ddsp_nsf_source", _ptr(f0), _ptr(rand_ini.contiguous().float()), _ptr(lin_w), _ptr(lin_b), L, int(upp),
+                  int(sr), float(sine_amp), _ptr(out))
+        return out
+
+    def nsf_noise_conv(self, src, w, b, K, stride, pad, T_out):
+        C = w.shape[0]
+        out = torch.empty(int(T_out), C, device=src.device, dtype=torch.float32)
+        self.call("ddsp_nsf_noise_conv", _ptr(src), src.numel(), _ptr(w), _ptr(b), C, int(K), int(stride), int(pad),
+                  int(T_out), _ptr(out))
+        return out
+
+    def nsf_post(self, x, w, b, K, slope):
+        T, C = x.shape
+        out = torch.empty(T, device=x.device, dtype=torch.float32)
+        self.call("ddsp_nsf_post", _ptr(x), _ptr(w), _ptr(b), T, C, int(K), float(slope), _ptr(out))
+        return out
+
+    def nsf_mean(self, terms):
+        a = terms[0]
+        out = torch.empty_like(a)
+        b = terms[1] if len(terms) > 1 else None
+        c = terms[2] if len(terms) > 2 else None
+        self.call("ddsp_nsf_mean", _ptr(a), _ptr(b), _ptr(c), len(terms), a.numel(), _ptr(out))
+        return out
+
+    def log_mel(self, frames, dft_table, mel_basis, clip):
+        n_frames, n_fft = frames.shape
+        n_mels = mel_basis.shape[0]
+        out = torch.empty(n_frames, n_mels, device=frames.device, dtype=torch.float32)
+        self.call("ddsp_log_mel", _ptr(frames), _ptr(dft_table), _ptr(mel_basis), n_frames, n_fft, n_mels, float(clip), _ptr(out))
+        return out
 
     # -- a15 optimiser -------------------------------------------------------------------------
     def adamw_step(self, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):

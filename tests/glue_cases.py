@@ -86,3 +86,66 @@ def crossfade_cases():
     return [(r.standard_normal(5000), r.standard_normal(4000), 4200),
             (r.standard_normal(300), r.standard_normal(1000), 0),          # fade over all of a
             (r.standard_normal(777), r.standard_normal(50), 740)]          # b shorter than a; fade 37 samples
+
+
+# ---- tier F: NSF-HiFiGAN post-net (nsf_hifigan/models.py) -------------------------------------------------------------------------
+# a small generator (fixtures stay small) with every structural feature of the shipped one: two transposed-convolution
+# geometries (k = 2u with u = 4 and u = 2), strided and 1-tap noise convolutions, three residual blocks per stage with
+# kernel sizes 3 / 7 / 11 and dilations 1 / 3 / 5
+NSF_CONFIG = {"resblock": "1", "upsample_rates": [4, 4, 2], "upsample_kernel_sizes": [8, 8, 4], "upsample_initial_channel": 64,
+              "resblock_kernel_sizes": [3, 7, 11], "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+              "num_mels": 16, "sampling_rate": 44100, "hop_size": 32, "n_fft": 128, "win_size": 128, "fmin": 40, "fmax": 16000}
+NSF_L = 23                      # frames
+NSF_WEIGHT_SEED, NSF_INPUT_SEED = 4242, 4243
+
+
+def nsf_state_dict(cfg=NSF_CONFIG, seed=NSF_WEIGHT_SEED):
+    """A generator checkpoint in the reference's key layout (weight_g / weight_v where it applies weight_norm), seeded.
+    Weight scales are chosen so that activations stay O(1) through the stack (the reference's 0.01-std init would make the
+    output vanish and test nothing)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def rn(*shape, scale=1.0):
+        return torch.randn(*shape, generator=g) * scale
+
+    def wn(prefix, shape, fan_in, gain=1.0):
+        v = rn(*shape)
+        sd[prefix + ".weight_v"] = v
+        sd[prefix + ".weight_g"] = (v.norm(dim=(1, 2), keepdim=True) * (0.9 + 0.2 * torch.rand(shape[0], 1, 1, generator=g))
+                                    * (gain / np.sqrt(fan_in)))
+        sd[prefix + ".bias"] = rn(shape[1] if "ups" in prefix else shape[0], scale=0.05)
+
+    ch = cfg["upsample_initial_channel"]
+    sd["m_source.l_linear.weight"] = rn(1, 9, scale=0.6)
+    sd["m_source.l_linear.bias"] = rn(1, scale=0.1)
+    wn("conv_pre", (ch, cfg["num_mels"], 7), cfg["num_mels"] * 7)
+    rates = cfg["upsample_rates"]
+    nk = len(cfg["resblock_kernel_sizes"])
+    for i, (u, k) in enumerate(zip(rates, cfg["upsample_kernel_sizes"])):
+        cin, cout = ch // 2 ** i, ch // 2 ** (i + 1)
+        wn(f"ups.{i}", (cin, cout, k), cin * k / u)
+        kk = 2 * int(np.prod(rates[i + 1:])) if i + 1 < len(rates) else 1
+        sd[f"noise_convs.{i}.weight"] = rn(cout, 1, kk, scale=0.5 / np.sqrt(kk))
+        sd[f"noise_convs.{i}.bias"] = rn(cout, scale=0.05)
+        for j, ks in enumerate(cfg["resblock_kernel_sizes"]):
+            for t in range(3):
+                wn(f"resblocks.{i * nk + j}.convs1.{t}", (cout, cout, ks), cout * ks)
+                wn(f"resblocks.{i * nk + j}.convs2.{t}", (cout, cout, ks), cout * ks)
+    wn("conv_post", (1, ch // 2 ** len(rates), 7), ch // 2 ** len(rates) * 7, gain=0.25)
+    return sd
+
+
+def nsf_inputs(cfg=NSF_CONFIG, L=NSF_L, seed=NSF_INPUT_SEED):
+    r = _rng(seed)
+    mel = f32(r.standard_normal((1, cfg["num_mels"], L)))
+    f0 = 220.0 * 2.0 ** (0.3 * np.sin(np.arange(L) / 5.0)) + 5.0 * r.standard_normal(L)
+    f0[3:6] = 0.0                                   # an unvoiced stretch
+    rand_ini = f32(r.random((1, 9)))
+    return mel, f32(f0[None]), rand_ini
+
+
+def nsf_audio(T=2000, seed=NSF_INPUT_SEED + 1):
+    r = _rng(seed)
+    t = np.arange(T) / 44100
+    return f32((0.4 * np.sin(2 * np.pi * 330 * t) + 0.05 * r.standard_normal(T))[None])

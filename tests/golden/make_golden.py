@@ -602,8 +602,47 @@ def tier_e():
     sys.path.remove(REF)
 
 
+# ------------------------------------------------------------------------------------------------
+def tier_f():
+    """the reference's own `nsf_hifigan/models.py` (imports only torch, numpy and its sibling env.py),
+    run on a seeded generator in the checkpoint key layout -> tests/golden/ref_enhancer.npz: the merged harmonic source,
+    every stage's output and the final audio.  torch.rand inside SineGen is replaced by the prepared draw for the call."""
+    import warnings
+    warnings.simplefilter("ignore")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import glue_cases as GC
+    for k in [k for k in sys.modules if k == "nsf_hifigan" or k.startswith("nsf_hifigan.")]:
+        del sys.modules[k]
+    sys.path.insert(0, REF)
+    import nsf_hifigan.models as M
+    from nsf_hifigan.env import AttrDict
+    sys.path.remove(REF)
+    assert M.__file__.startswith(REF)
+    h = AttrDict(GC.NSF_CONFIG)
+    gen = M.Generator(h)
+    gen.load_state_dict(GC.nsf_state_dict(), strict=True)        # the checkpoint layout: weight_g / weight_v keys
+    gen.eval()
+    gen.remove_weight_norm()                                      # what nsf_hifigan.models.load_model does
+    mel, f0, rand_ini = GC.nsf_inputs()
+    stages = []
+    hooks = [gen.resblocks[i * gen.num_kernels + gen.num_kernels - 1].register_forward_hook(
+        lambda m, i_, o: stages.append(o.detach().clone())) for i in range(gen.num_upsamples)]
+    orig_rand = torch.rand
+    torch.rand = lambda *a, **k: rand_ini.clone()
+    try:
+        with torch.no_grad():
+            src = gen.m_source(f0, gen.upp)
+            audio = gen(mel, f0)
+    finally:
+        torch.rand = orig_rand
+        for hk in hooks:
+            hk.remove()
+    save("ref_enhancer.npz", source=src[0, :, 0], audio=audio[0, 0],
+         last_resblock_out=[s[0].t().contiguous()[::7] for s in stages][-1], n_params=sum(p.numel() for p in gen.parameters()))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["a", "b", "c", "d", "e"]
+    which = sys.argv[1:] or ["a", "b", "c", "d", "e", "f"]
     torch.set_num_threads(4)
     if "a" in which:
         tier_a()
@@ -615,3 +654,5 @@ if __name__ == "__main__":
         tier_d()
     if "e" in which:
         tier_e()
+    if "f" in which:
+        tier_f()

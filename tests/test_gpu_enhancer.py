@@ -1,0 +1,149 @@
+"""SURVEY 8(f) rank 1 on the device: the NSF-HiFiGAN post-net (source module, generator, log-mel front end, Enhancer.enhance)
+against fixtures produced by the reference's own nsf_hifigan/models.py (tests/golden/ref_enhancer.npz) and against the CPU
+oracle.  Unpinned third-party boundaries: librosa's mel filter bank, torchaudio's resampler (absent from the image)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import glue_cases as GC
+from conftest import GOLDEN, rms
+from oracle import enhancer as OE
+from oracle import resample as OR
+
+pytestmark = pytest.mark.gpu
+UPP = int(np.prod(GC.NSF_CONFIG["upsample_rates"]))
+
+
+def _generator(dev):
+    from enhancer import AttrDict, Generator
+    return Generator(AttrDict(GC.NSF_CONFIG), GC.nsf_state_dict()).to(dev)
+
+
+def test_source_module_against_reference(ctx, dev):
+    z = np.load(os.path.join(GOLDEN, "ref_enhancer.npz"))
+    sd = GC.nsf_state_dict()
+    mel, f0, ri = GC.nsf_inputs()
+    r = ri[0].clone()
+    r[0] = 0
+    src = ctx.nsf_source(f0[0].to(dev), r.to(dev), sd["m_source.l_linear.weight"].reshape(-1).to(dev),
+                         sd["m_source.l_linear.bias"].to(dev), UPP, 44100, 0.1)
+    assert src.shape == (GC.NSF_L * UPP,)
+    assert float((src.cpu() - torch.from_numpy(z["source"])).abs().max()) < 2e-6
+    # a long track: the fp64 phase stays exact over a minute of audio
+    L, upp = 5000, 512
+    f0l = torch.full((1, L), 440.0)
+    want = OE.sine_source(sd, f0l, upp, 44100, ri)[0, :, 0]
+    got = ctx.nsf_source(f0l[0].to(dev), r.to(dev), sd["m_source.l_linear.weight"].reshape(-1).to(dev),
+                         sd["m_source.l_linear.bias"].to(dev), upp, 44100, 0.1)
+    assert float((got.cpu() - want).abs().max()) < 5e-6
+
+
+def test_generator_against_reference(dev, lib_path):
+    z = np.load(os.path.join(GOLDEN, "ref_enhancer.npz"))
+    gen = _generator(dev)
+    mel, f0, ri = GC.nsf_inputs()
+    audio = gen(mel.to(dev), f0.to(dev), rand_ini=ri[0])
+    assert audio.shape == (1, 1, GC.NSF_L * UPP)
+    want = torch.from_numpy(z["audio"])
+    err = rms(audio[0, 0].cpu() - want)
+    assert err < 2e-5 * max(rms(want), 1e-3) + 1e-6, (err, rms(want))
+    assert float((audio[0, 0].cpu() - want).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("L", [1, 2, 64, 173])
+def test_generator_against_oracle_lengths(dev, lib_path, L):
+    gen = _generator(dev)
+    mel, f0, ri = GC.nsf_inputs(L=L, seed=77 + L)
+    want = OE.generator(GC.nsf_state_dict(), GC.NSF_CONFIG, mel, f0, ri)
+    got = gen(mel.to(dev), f0.to(dev), rand_ini=ri[0])
+    assert got.shape == want.shape
+    assert float((got.cpu() - want).abs().max()) < 1e-4, L
+
+
+def test_conv1d_building_block(ctx, dev):
+    """`ddsp_conv1d` alone against torch's conv1d (fp64): kernel sizes 1..11, dilations, leaky-ReLU on load, residual."""
+    g = torch.Generator().manual_seed(5)
+    for (T, Cin, Cout, k, d, slope, res) in [(50, 16, 24, 3, 1, 1.0, False), (333, 32, 32, 7, 3, 0.1, True),
+                                             (129, 64, 8, 11, 5, 0.1, False), (7, 4, 4, 1, 1, 0.5, True),
+                                             (2000, 128, 64, 7, 1, 1.0, False)]:
+        x = torch.randn(T, Cin, generator=g)
+        w = torch.randn(Cout, Cin, k, generator=g) / np.sqrt(Cin * k)
+        b = torch.randn(Cout, generator=g)
+        r = torch.randn(T, Cout, generator=g) if res else None
+        want = torch.nn.functional.conv1d(torch.nn.functional.leaky_relu(x.double(), slope).t()[None], w.double(), b.double(),
+                                          dilation=d, padding=(k * d - d) // 2)[0].t()
+        if res:
+            want = want + r.double()
+        wp = w.permute(0, 2, 1).reshape(Cout, -1).contiguous()
+        got = ctx.conv1d(x.to(dev), wp.to(dev), b.to(dev), k, d, slope, residual=None if r is None else r.to(dev))
+        assert float((got.cpu().double() - want).abs().max()) < 2e-5, (T, Cin, Cout, k, d)
+    with pytest.raises(ValueError):
+        ctx.conv1d(x.to(dev), wp.to(dev), b.to(dev), 2, 1, 1.0)          # even tap counts are not "same"-paddable
+
+
+def test_log_mel_against_oracle(dev, lib_path):
+    """`STFT.get_mel` (device) against the oracle's torch.stft formulation with the same (restated) mel filter bank."""
+    from enhancer import STFT, mel_filterbank
+    h = GC.NSF_CONFIG
+    st = STFT(h["sampling_rate"], h["num_mels"], h["n_fft"], h["win_size"], h["hop_size"], h["fmin"], h["fmax"])
+    basis = torch.from_numpy(mel_filterbank(h["sampling_rate"], h["n_fft"], h["num_mels"], h["fmin"], h["fmax"]))
+    # the filter bank has the properties librosa's has: non-negative triangles, one peak per band, Slaney area normalisation
+    assert basis.shape == (h["num_mels"], h["n_fft"] // 2 + 1) and float(basis.min()) >= 0
+    assert all(int((basis[i] > 0).sum()) >= 1 for i in range(h["num_mels"]))
+    for T in (2000, 4096, 100):
+        y = GC.nsf_audio(T)
+        want = OE.log_mel(y, h, basis)
+        got = st.get_mel(y.to(dev))
+        assert got.shape == want.shape == (1, h["num_mels"], want.shape[-1])
+        assert float((got.cpu() - want).abs().max()) < 2e-4, T
+
+
+def test_enhancer_end_to_end(dev, lib_path, tmp_path):
+    """`Enhancer('nsf-hifigan', ckpt, device).enhance(...)` from a checkpoint + config.json on disk (the reference's file
+    layout), with and without the adaptive-key resampling and the silent front, against the same pipeline assembled from the
+    oracle's parts on the CPU."""
+    from enhancer import Enhancer, mel_filterbank
+    h = dict(GC.NSF_CONFIG)
+    with open(tmp_path / "config.json", "w") as fh:
+        json.dump(h, fh)
+    torch.save({"generator": GC.nsf_state_dict()}, tmp_path / "model")
+    enh = Enhancer("nsf-hifigan", str(tmp_path / "model"), device=dev)
+    assert enh.enhancer_sample_rate == 44100 and enh.enhancer_hop_size == 32
+    sd = GC.nsf_state_dict()
+    basis = torch.from_numpy(mel_filterbank(h["sampling_rate"], h["n_fft"], h["num_mels"], h["fmin"], h["fmax"]))
+    ri = torch.tensor([0.0, 0.3, 0.7, 0.1, 0.9, 0.5, 0.2, 0.8, 0.4])
+
+    def cpu_pipeline(audio, sr, f0, hop, key, silence_front):
+        start = int(silence_front * sr / hop)
+        rsf = start * hop / sr
+        audio = audio[:, int(np.round(rsf * sr)):]
+        f0 = f0[:, start:, :]
+        fac = 2 ** (-float(key) / 12)
+        asr = 100 * int(np.round(44100 / fac / 100))
+        rf = 44100 / asr
+        a = audio if sr == asr else OR.resample(audio, sr, asr, 128)
+        n_frames = int(a.size(-1) // 32 + 1)
+        f = f0.squeeze(0).squeeze(-1).numpy().copy() * rf
+        t0 = (hop / sr) * np.arange(len(f)) / rf
+        t1 = (32 / 44100) * np.arange(n_frames)
+        fr = torch.from_numpy(np.interp(t1, t0, f, left=f[0], right=f[-1])).unsqueeze(0).float()
+        mel = OE.log_mel(a, h, basis)
+        out = OE.generator(sd, h, mel, fr[:, :mel.size(-1)], ri[None]).reshape(1, -1)
+        out = OR.resample(out, asr, 44100, 128) if fac != 0 and asr != 44100 else out
+        if start > 0:
+            out = torch.nn.functional.pad(out, (int(np.round(44100 * rsf)), 0))
+        return out
+
+    T, hop = 4096, 512
+    audio = GC.nsf_audio(T)
+    f0 = torch.full((1, T // hop, 1), 300.0)
+    for key, sf in ((0, 0), (4, 0), (0, 0.03)):
+        got, sr_o = enh.enhance(audio.to(dev), 44100, f0.to(dev), hop, adaptive_key=key, silence_front=sf, rand_ini=ri)
+        want = cpu_pipeline(audio, 44100, f0, hop, key, sf)
+        assert sr_o == 44100 and got.shape == want.shape, (key, sf, got.shape, want.shape)
+        assert float((got.cpu() - want).abs().max()) < 5e-4, (key, sf)
+    with pytest.raises(ValueError):
+        Enhancer("other", str(tmp_path / "model"))

@@ -131,5 +131,5 @@ def test_enhancer_surface():
     from enhancer import Enhancer
     with pytest.raises(ValueError):
         Enhancer("other", "x")
-    with pytest.raises(NotImplementedError):
-        Enhancer("nsf-hifigan", "x")
+    with pytest.raises(FileNotFoundError):          # like the reference: the config.json beside the checkpoint is read first
+        Enhancer("nsf-hifigan", "/nonexistent/model")

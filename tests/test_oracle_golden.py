@@ -338,3 +338,22 @@ def test_offline_glue_against_reference_run():
     for i, (a, b, idx) in enumerate(GC.crossfade_cases()):
         assert np.array_equal(RT.slice_cross_fade(a, b, idx), z[f"xfade_{i}"]), i
         assert np.array_equal(infer_offline.cross_fade(a, b, idx), z[f"xfade_{i}"]), i
+
+
+# ---- tier F: the NSF-HiFiGAN post-net against the reference's own nsf_hifigan/models.py ------------------------------------------
+def test_enhancer_oracle_against_reference_run():
+    import glue_cases as GC
+    from oracle import enhancer as OE
+    g = load("ref_enhancer.npz")
+    sd = GC.nsf_state_dict()
+    mel, f0, ri = GC.nsf_inputs()
+    upp = int(np.prod(GC.NSF_CONFIG["upsample_rates"]))
+    src = OE.sine_source(sd, f0, upp, GC.NSF_CONFIG["sampling_rate"], ri)
+    assert src.shape == (1, GC.NSF_L * upp, 1)
+    assert (src[0, :, 0] - g["source"]).abs().max() < 1e-6
+    audio = OE.generator(sd, GC.NSF_CONFIG, mel, f0, ri)
+    assert audio.shape == (1, 1, GC.NSF_L * upp)
+    assert (audio[0, 0] - g["audio"]).abs().max() < 1e-5
+    assert 0.05 < rms(g["audio"]) < 0.5                      # the fixture is not saturated by the final tanh
+    # the unvoiced stretch: f0 = 0 gives a constant phase (only the initial offsets), not silence - as in the reference
+    assert rms(g["source"][3 * upp:6 * upp]) > 0
