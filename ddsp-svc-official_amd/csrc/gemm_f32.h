@@ -45,6 +45,7 @@ struct Args {
     int64_t sA_hi, sA_lo, sB_hi, sB_lo;
     // conv3 / convK mode
     int Fr, Cin;
+    int tap_shift;        // A_CONV3: 0 = centred taps (frames -1, 0, +1), -1 = causal taps (frames -2, -1, 0)
     int ktaps, dil;       // A_CONVK
     float in_slope;       // A_CONVK: leaky-ReLU slope applied to A on load (1 = none)
     const float* zeros;   // >= Cin + 32 zero floats (DMA kernel, conv3 mode: source of the taps that fall off an utterance)
@@ -156,8 +157,9 @@ __global__ void __launch_bounds__(64 * NW) kernel(Args g, Epi epi) {
                     // k = tap*Cin + c ; Cin % 4 == 0 so a float4 never straddles taps
                     if (m < g.M && k < g.K) {
                         const int tap = k / g.Cin, c = k - tap * g.Cin;
-                        const int f = m % g.Fr + tap - 1;
-                        if (f >= 0 && f < g.Fr) v = *(const f32x4_u*)(A + (int64_t)(m + tap - 1) * g.lda + c);
+                        const int off = tap - 1 + g.tap_shift;
+                        const int f = m % g.Fr + off;
+                        if (f >= 0 && f < g.Fr) v = *(const f32x4_u*)(A + (int64_t)(m + off) * g.lda + c);
                     }
                 } else if (A_MODE == A_CONVK) {
                     if (m < g.M && k < g.K) {
@@ -419,8 +421,13 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ?
                 if constexpr (A_MODE == A_CONV3) {
                     if (i < PA) {
                         const int f = m % g.Fr;
-                        src_m1[i < PA ? i : 0] = f >= 1 ? src[i] - g.lda : g.zeros + slot * 4;
-                        src_p1[i < PA ? i : 0] = f + 1 < g.Fr ? src[i] + g.lda : g.zeros + slot * 4;
+                        // taps at frames f - 1 + s, f + s, f + 1 + s (s = tap_shift); off the utterance -> the zero page
+                        const int s = g.tap_shift;
+                        const float* base = src[i];
+                        const float* zp = g.zeros + slot * 4;
+                        src_m1[i < PA ? i : 0] = (f - 1 + s >= 0 && f - 1 + s < g.Fr) ? base + (int64_t)(s - 1) * g.lda : zp;
+                        src_p1[i < PA ? i : 0] = (f + 1 + s >= 0 && f + 1 + s < g.Fr) ? base + (int64_t)(s + 1) * g.lda : zp;
+                        src[i] = (f + s >= 0 && f + s < g.Fr) ? base + (int64_t)s * g.lda : zp;
                     }
                 }
             } else {
@@ -795,6 +802,7 @@ inline Args make(const float* A, int64_t lda, const float* B, int64_t ldb, int M
     g.sA_hi = g.sA_lo = g.sB_hi = g.sB_lo = 0;
     g.Fr = 1;
     g.Cin = 4;
+    g.tap_shift = 0;
     g.ktaps = 3;
     g.dil = 1;
     g.in_slope = 1.f;

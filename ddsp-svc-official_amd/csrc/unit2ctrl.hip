@@ -429,6 +429,61 @@ __global__ void __launch_bounds__(256) attn_denominator_kernel(const float* __re
     if (lane == 0) dinv[r] = 1.0f / (s + 1e-8f);
 }
 
+// ---- causal linear attention (ddsp/pcmer.py:170-188, `c: true`), inference ---------------------------------------------------
+// out[n] = (q'_n . sum_{m<=n} k'_m (x) v_m) / (q'_n . (sum_{m<=n} k'_m + 1e-6)).  One workgroup per (utterance, head) walks
+// the frames in order; thread t owns channel e = t & 63 of rows j = (t >> 6) + 4 i of the running 266 x 64 state (67 registers).
+// `fast_transformers.CausalDotProduct` (the numerator) is a third-party CUDA extension that is not in the image: it is
+// restated from its definition; the normaliser is the reference's own code.  Correct-first: one frame per step, two barriers.
+__global__ void __launch_bounds__(256) causal_attention_kernel(const float* __restrict__ qf, const float* __restrict__ kf,
+                                                               const float* __restrict__ v, int Fr, float* __restrict__ out) {
+    constexpr int ROWS = (NF + 3) / 4;       // 67
+    __shared__ float sq[LDF], sk[LDF], sv[DH], part[4 * DH], dpart[4];
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int t = threadIdx.x, e = t & 63, r0 = t >> 6;
+    float S[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) S[i] = 0.f;
+    float ksum[2] = {0.f, 0.f};              // running key sums of features t and t + 256
+    for (int n = 0; n < Fr; ++n) {
+        const int64_t row8 = ((int64_t)b * Fr + n) * H + h;
+        for (int j = t; j < LDF; j += 256) {
+            sq[j] = qf[row8 * LDF + j];
+            sk[j] = kf[row8 * LDF + j];
+        }
+        if (t < DH) sv[t] = v[((int64_t)b * Fr + n) * INNER + h * DH + t];
+        __syncthreads();
+        const float ve = sv[e];
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            const int j = r0 + 4 * i;
+            if (j < NF) {
+                S[i] = fmaf(sk[j], ve, S[i]);
+                acc = fmaf(sq[j], S[i], acc);
+            }
+        }
+        part[r0 * DH + e] = acc;
+        // denominator: q' . (cumulative k' + eps), features t and t + 256
+        float d = 0.f;
+        if (t < NF) {
+            ksum[0] += sk[t];
+            d = sq[t] * (ksum[0] + 1e-6f);
+        }
+        if (t + 256 < NF) {
+            ksum[1] += sk[t + 256];
+            d = fmaf(sq[t + 256], ksum[1] + 1e-6f, d);
+        }
+        d = wave_sum(d);
+        if ((t & 63) == 0) dpart[t >> 6] = d;
+        __syncthreads();
+        if (t < DH) {
+            const float num = (part[t] + part[DH + t]) + (part[2 * DH + t] + part[3 * DH + t]);
+            const float den = (dpart[0] + dpart[1]) + (dpart[2] + dpart[3]);
+            out[((int64_t)b * Fr + n) * INNER + h * DH + t] = num * (1.0f / den);
+        }
+    }
+}
+
 struct EpiAttnOut {  // out[(b*Fr+n)*512 + h*64 + e] = dinv[(b*Fr+n)*8+h] * acc   (z = b*8+h, m = n, col = e); dinv null -> 1
     float* out;
     const float* dinv;
@@ -469,7 +524,8 @@ constexpr int DW_RUN = 32;
 template <bool SILU, bool FLIP>
 __global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, int B, int Fr,
-                                                     float* __restrict__ out, float* __restrict__ pre, int wsc, int wst) {
+                                                     float* __restrict__ out, float* __restrict__ pre, int wsc, int wst,
+                                                     int left) {   // left = DWK / 2: centred taps; DWK - 1: causal taps (frames t-30 .. t)
     const int c = blockIdx.x * 256 + threadIdx.x;       // channel (INNER = 512 -> 2 blocks in x)
     const int runs = (Fr + DW_RUN - 1) / DW_RUN;
     const int b = blockIdx.y / runs, f0 = (blockIdx.y % runs) * DW_RUN;
@@ -480,7 +536,7 @@ __global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ x
     float win[DW_RUN + DWK - 1];
 #pragma unroll
     for (int i = 0; i < DW_RUN + DWK - 1; ++i) {
-        const int f = f0 + i - DWK / 2;
+        const int f = f0 + i - left;
         win[i] = (f >= 0 && f < Fr) ? xb[(int64_t)f * INNER] : 0.f;
     }
     const float bi = FLIP ? 0.f : bias[c];
@@ -1032,7 +1088,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
     // conv1 reads the caller's fp32 units and pw2 the depthwise conv's fp32 output: those two split A in the kernel.
     const bool presplit = lin_math == DDSP_MATH_SPLIT_BF16 && ctx->math != 4 && fuse_glu && M >= 8192 && w.n_unit % 32 == 0 &&
                           w.n_unit + 32 <= DDSP_ZERO_FLOATS && w.n_out >= 256 && ((uintptr_t)in.units % 16) == 0;
-    const bool attn_bf16 = !bf.l[0].pre && lin_math == DDSP_MATH_SPLIT_BF16 && B * H >= 256;
+    const bool attn_bf16 = !bf.l[0].pre && lin_math == DDSP_MATH_SPLIT_BF16 && B * H >= 256 && !w.causal;
     const int asplit = presplit ? 1 : 0;
     {   // weight preparation, one launch (u2c_prepare_kernel)
         PrepArgs pa;
@@ -1078,6 +1134,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
     {
         gemm::Args g = gemm::make(in.units, w.n_unit, bf.w1, 3 * w.n_unit, iM, D, 3 * w.n_unit);
         set_b(g, bf.w1, 0);
+        g.tap_shift = w.causal ? -1 : 0;
         g.Fr = (int)Fr;
         g.Cin = w.n_unit;
         g.zeros = zero_page;
@@ -1094,6 +1151,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
     {
         gemm::Args g = gemm::make(bf.t2, D, bf.w2, 3 * D, iM, D, 3 * D);
         set_b(g, bf.w2, asplit);
+        g.tap_shift = w.causal ? -1 : 0;
         g.Fr = (int)Fr;
         g.Cin = D;
         g.zeros = zero_page;
@@ -1127,6 +1185,21 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
                  performer_kv_bf16(st, b.k, b.v, p3, (int)B, (int)Fr, b.cx, b.ks));
             PROF(PF_U2C_GEMM_ATTNOUT, 4.0 * M8 * NF * DH, 4.0 * M * 2 * INNER,
                  performer_q_bf16(st, b.q, p3, b.cx, b.ks, (int)B, (int)Fr, b.attn, 0, asplit));
+        } else if (!b.pre && w.causal) {
+            // causal mode (inference only): feature maps through the GEMM + row kernels of the training path, then the
+            // sequential causal attention kernel
+            gemm::Args g = gemm::make(b.q, DH, L.proj, DH, (int)M8, NF, DH);
+            gemm::EpiStore e{b.qf, LDF, nullptr, 1, 0, 0};
+            PROF(PF_U2C_GEMM_FEAT, 2.0 * M8 * NF * DH, 4.0 * M8 * (DH + NF), (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
+            g.A = b.k;
+            e.C = b.kf;
+            PROF(PF_U2C_GEMM_FEAT, 2.0 * M8 * NF * DH, 4.0 * M8 * (DH + NF), (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
+            PROF(PF_U2C_ROWWISE, 0, 4.0 * M8 * (2 * NF + DH),
+                 hipLaunchKernelGGL(feature_map_kernel<true>, dim3(rows8_g), dim3(256), 0, st, b.qf, b.q, M8));
+            PROF(PF_U2C_ROWWISE, 0, 4.0 * M8 * (2 * NF + DH),
+                 hipLaunchKernelGGL(feature_map_kernel<false>, dim3(rows8_g), dim3(256), 0, st, b.kf, b.k, M8));
+            PROF(PF_U2C_GEMM_ATTNOUT, 4.0 * M8 * NF * DH, 4.0 * M8 * (2 * NF + 2 * DH),
+                 hipLaunchKernelGGL(causal_attention_kernel, dim3((unsigned)(B * H)), dim3(256), 0, st, b.qf, b.kf, b.v, (int)Fr, b.attn));
         } else if (!b.pre) {
             // inference: fused feature maps + linear attention (performer_attn.hip); q'/k' never reach HBM
             PROF(PF_U2C_GEMM_CTX, 4.0 * M8 * NF * DH, 4.0 * M * 2 * INNER,
@@ -1205,7 +1278,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         }
         PROF(PF_U2C_ROWWISE, 2.0 * M * INNER * DWK, 8.0 * M * INNER,
              hipLaunchKernelGGL((dwconv_kernel<true, false>), dim3(INNER / 256, (unsigned)(B * ((Fr + DW_RUN - 1) / DW_RUN))),
-                                dim3(256), 0, st, b.glu, bf.wdw + (size_t)l * DWK * INNER, L.cm_dw_b, (int)B, (int)Fr, b.dwo, b.pre, 1, INNER));
+                                dim3(256), 0, st, b.glu, bf.wdw + (size_t)l * DWK * INNER, L.cm_dw_b, (int)B, (int)Fr, b.dwo, b.pre, 1, INNER, w.causal ? DWK - 1 : DWK / 2));
         {
             gemm::Args g = gemm::make(b.dwo, INNER, L.cm_pw2_w, INNER, iM, D, INNER);
             set_b(g, bf.wpw2 + (size_t)l * D * INNER, 0);
@@ -1240,6 +1313,7 @@ static int check_inputs(ddsp_ctx* ctx, const ddsp_u2c_weights* wp, const float* 
     DDSP_REQUIRE(ctx, n_mix > 0 || (spk_id && (n_spk_id == 1 || n_spk_id == B)), "ddsp_unit2ctrl: spk_id must hold 1 or B ids");
     DDSP_REQUIRE(ctx, n_mix == 0 || (mix_ids_host && mix_w_host), "ddsp_unit2ctrl: mix arrays missing");
     DDSP_REQUIRE(ctx, wp->n_unit >= 4 && wp->n_unit % 4 == 0 && wp->n_out >= 1 && wp->n_spk >= 1, "ddsp_unit2ctrl: bad widths");
+    DDSP_REQUIRE(ctx, wp->causal == 0 || wp->causal == 1, "ddsp_unit2ctrl: causal must be 0 or 1");
     for (int k = 0; k < n_mix; ++k)
         DDSP_REQUIRE(ctx, mix_ids_host[k] >= 1 && mix_ids_host[k] <= wp->n_spk, "ddsp_unit2ctrl: mixed speaker id out of range");
     in.units = units;
@@ -1359,6 +1433,7 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
                           n_mix, B, Fr, in);
     if (rc) return rc;
     DDSP_REQUIRE(ctx, d_ctrl && grads_host, "ddsp_unit2ctrl_bwd: null argument");
+    DDSP_REQUIRE(ctx, !wp->causal, "ddsp_unit2ctrl_bwd: the causal network (c: true) is built for inference only");
     if ((rc = ddsp_take_dev_error(ctx))) return rc;
     if (B == 0) return DDSP_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -1439,7 +1514,7 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
                            (int64_t)INNER * DWK, GLP(cm_dw_w));
         if ((rc = colsum(ctx, st, dB512, INNER, M, INNER, nullptr, 0, cpart, GLP(cm_dw_b)))) return rc;
         hipLaunchKernelGGL((dwconv_kernel<false, true>), dim3(INNER / 256, (unsigned)(B * ((Fr + DW_RUN - 1) / DW_RUN))),
-                           dim3(256), 0, st, dB512, L.cm_dw_w, nullptr, (int)B, (int)Fr, dC512, nullptr, DWK, 1);   // d_glu
+                           dim3(256), 0, st, dB512, L.cm_dw_w, nullptr, (int)B, (int)Fr, dC512, nullptr, DWK, 1, DWK / 2);   // d_glu
         hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for(M * INNER)), dim3(256), 0, st, b.g1, dC512, M, dG1);
         if ((rc = wgrad(ctx, st, dG1, 2 * INNER, 2 * INNER, b.y2, D, D, M, wpart, GLP(cm_pw1_w), D, 0))) return rc;
         if ((rc = colsum(ctx, st, dG1, 2 * INNER, M, 2 * INNER, nullptr, 0, cpart, GLP(cm_pw1_b)))) return rc;

@@ -131,9 +131,10 @@ def split_to_dict(tensor, tensor_splits):
 class Unit2Control(nn.Module):
     def __init__(self, ndim_feat_i, n_spk, output_splits, c=False):
         super().__init__()
-        if c:
-            raise ValueError("causal mode (c: true) is not built: the reference's causal Conv1dEx / "
-                             "fast_transformers semantics are unpinned (see DESIGN.md)")
+        # c = True: causal convolutions (taps at frames t-k+1 .. t) and causal linear attention, inference only.  The two
+        # third-party primitives behind it (extorch.Conv1dEx(causal=True), fast_transformers.CausalDotProduct) are not in
+        # the image: they are restated from their definitions, parity at that boundary is unpinned.
+        self.causal = bool(c)
         self.n_unit = int(ndim_feat_i)
         self.n_spk = int(n_spk)
         self.output_splits = dict(output_splits)
@@ -182,6 +183,8 @@ class Unit2Control(nn.Module):
         """Gradients of every parameter for an upstream d_ctrl (B,Fr,n_out): {parameter tensor: gradient tensor}.
         `ctx`: the context of the forward call (autograd runs backward on its own thread; reusing the forward's
         context keeps one scratch arena and one profiler per model call)."""
+        if self.causal:
+            raise NotImplementedError("the causal network (c: true) is built for inference only")
         ctx = ctx or hipddsp.context_for(units.device)
         w, keep = self._weights_struct()
         g = hipddsp.U2CWeights()
@@ -218,6 +221,7 @@ class Unit2Control(nn.Module):
         w.volume_w, w.volume_b = p(self.volume_embed.weight), p(self.volume_embed.bias)
         w.spk_table = p(self.spk_embed.weight)
         w.n_spk, w.n_unit, w.n_out = self.n_spk, self.n_unit, self.n_out
+        w.causal = 1 if self.causal else 0
         for i, layer in enumerate(self.dec_post[0].net):
             a, cm = layer.attn, layer.local_mixer.net
             vals = dict(norm_w=layer.norm.weight, norm_b=layer.norm.bias,

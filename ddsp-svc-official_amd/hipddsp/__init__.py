@@ -31,7 +31,7 @@ class U2CWeights(_c.Structure):
         [(n, _vp) for n in ("prenet_conv1_w", "prenet_conv1_b", "prenet_gn_w", "prenet_gn_b",
                             "prenet_conv2_w", "prenet_conv2_b",
                             "f0_w", "f0_b", "phase_w", "phase_b", "volume_w", "volume_b", "spk_table")]
-        + [("n_spk", _int), ("n_unit", _int), ("n_out", _int)]
+        + [("n_spk", _int), ("n_unit", _int), ("n_out", _int), ("causal", _int)]
         + [(f"l{i}_{n}", _vp) for i in range(3) for n in (
             "norm_w", "norm_b", "q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "proj", "out_w", "out_b",
             "cm_ln_w", "cm_ln_b", "cm_pw1_w", "cm_pw1_b", "cm_dw_w", "cm_dw_b", "cm_pw2_w", "cm_pw2_b")]

@@ -43,7 +43,7 @@ def combsub_forward(sd, cfg, units, f0_frames, volume, spk_id, spk_mix_dict=None
     phase_frames = 2 * np.pi * rot[:, ::hop]
     if ctrl_override is None:
         ctrl = unit2control(_ctrl_state(sd), units, f0_frames, phase_frames, volume, spk_id, spk_mix_dict,
-                            SPLITS["CombSub"](cfg))
+                            SPLITS["CombSub"](cfg), causal=bool(cfg.get("c", False)))
     else:
         ctrl = ctrl_override
     group_delay = np.pi * torch.tanh(ctrl["group_delay"])
@@ -71,7 +71,7 @@ def sins_forward(sd, cfg, units, f0_frames, volume, spk_id, spk_mix_dict=None, i
     phase_frames = phase[:, ::hop]
     if ctrl_override is None:
         ctrl = unit2control(_ctrl_state(sd), units, f0_frames, phase_frames, volume, spk_id, spk_mix_dict,
-                            SPLITS["Sins"](cfg))
+                            SPLITS["Sins"](cfg), causal=bool(cfg.get("c", False)))
     else:
         ctrl = ctrl_override
     amps = torch.exp(ctrl["amplitudes"]) / 128
@@ -97,7 +97,7 @@ def combsubfast_forward(sd, cfg, units, f0_frames, volume, spk_id, spk_mix_dict=
     phase_frames = 2 * np.pi * rot[:, ::hop]
     if ctrl_override is None:
         ctrl = unit2control(_ctrl_state(sd), units, f0_frames, phase_frames, volume, spk_id, spk_mix_dict,
-                            SPLITS["CombSubFast"](cfg))
+                            SPLITS["CombSubFast"](cfg), causal=bool(cfg.get("c", False)))
     else:
         ctrl = ctrl_override
     comb = dsp.sinc_comb(rot, f0, sr, zero_unvoiced=True)

@@ -641,8 +641,66 @@ def tier_f():
          last_resblock_out=[s[0].t().contiguous()[::7] for s in stages][-1], n_params=sum(p.numel() for p in gen.parameters()))
 
 
+# ------------------------------------------------------------------------------------------------
+def tier_g():
+    """Causal mode (`c: true`): the reference's CombSub built with c=True.  Its own code runs
+    (`causal_linear_attention`'s cumulative normaliser, the module wiring); the two third-party primitives it calls are
+    stand-ins written from their definitions - `extorch.Conv1dEx(causal=True)` as a convolution over the current and the
+    k-1 previous frames, `fast_transformers.causal_product.CausalDotProduct` as q_n . sum_{m<=n} k_m (x) v_m - so parity at
+    that boundary stays UNPINNED.  -> model_CombSub_causal.npz"""
+    import warnings
+    import torch.nn as nn
+    import torch.nn.functional as F
+    warnings.simplefilter("ignore")
+    _placeholders()
+
+    class Conv1dExCausal(nn.Conv1d):
+        def __init__(self, *a, causal=False, padding="same", **k):
+            self._causal = bool(causal)
+            super().__init__(*a, padding=0 if causal else padding, **k)
+
+        def forward(self, x):
+            if self._causal:
+                x = F.pad(x, (self.kernel_size[0] - 1, 0))
+            return super().forward(x)
+
+    class CausalDotProduct:
+        @staticmethod
+        def apply(q, k, v):
+            ctx = torch.einsum("bhnm,bhne->bhnme", k, v).cumsum(dim=2)
+            return torch.einsum("bhnm,bhnme->bhne", q, ctx)
+
+    sys.modules["extorch"].Conv1dEx = Conv1dExCausal
+    sys.modules["fast_transformers.causal_product"].CausalDotProduct = CausalDotProduct
+    for k in [k for k in sys.modules if k == "ddsp" or k.startswith("ddsp.")]:
+        del sys.modules[k]
+    import synthetic
+    m, cfg = synthetic.build_model("CombSub", seed=synthetic.BASE_SEED + 7)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    for k in [k for k in sys.modules if k == "ddsp" or k.startswith("ddsp.")]:
+        del sys.modules[k]
+    sys.path.insert(0, REF)
+    import ddsp.vocoder as V
+    sys.path.remove(REF)
+    assert V.__file__.startswith(REF)
+    ref = V.CombSub(SR, HOP, cfg["n_mag_allpass"], cfg["n_mag_harmonic"], cfg["n_mag_noise"], 256, cfg["n_spk"], c=True)
+    ref.load_state_dict(sd, strict=True)
+    ref.eval()
+    B, Fr = 2, 24
+    inp = synthetic.make_inputs(synthetic.BASE_SEED + 12, B, Fr)
+    grabbed = {}
+    h = ref.unit2ctrl.register_forward_hook(lambda mod, i, o: grabbed.update(o))
+    with torch.no_grad(), _InjectNoise(inp["noise"]):
+        sig, ph, (hm, nz) = ref(inp["units"], inp["f0"], inp["volume"], inp["spk_id"], infer=True)
+    h.remove()
+    save("model_CombSub_causal.npz", signal=sig, ctrl=torch.cat(list(grabbed.values()), dim=-1), harmonic=hm[:, ::7], noise=nz[:, ::7],
+         seed_weights=synthetic.BASE_SEED + 7, seed_inputs=synthetic.BASE_SEED + 12)
+    for k in [k for k in sys.modules if k == "ddsp" or k.startswith("ddsp.") or k in ("extorch", "fast_transformers", "fast_transformers.causal_product")]:
+        del sys.modules[k]
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["a", "b", "c", "d", "e", "f"]
+    which = sys.argv[1:] or ["a", "b", "c", "d", "e", "f", "g"]
     torch.set_num_threads(4)
     if "a" in which:
         tier_a()
@@ -656,3 +714,5 @@ if __name__ == "__main__":
         tier_e()
     if "f" in which:
         tier_f()
+    if "g" in which:
+        tier_g()

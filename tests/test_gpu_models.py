@@ -456,3 +456,38 @@ def test_long_utterance_against_oracle(dev, lib_path, name, Fr):
     dph = dph - torch.round(dph)
     assert float(dph.abs().max()) < 2e-5, float(dph.abs().max())
     assert rms(sig_o) > 1e-3
+
+
+def test_causal_mode_against_reference_fixture(dev, lib_path):
+    """`c: true`, inference: causal conv taps, causal depthwise conv and the causal linear attention on
+    the device against the reference's CombSub(c=True) run (fixture; the two third-party causal primitives were stand-ins
+    there) and against the oracle at a full-size batch (the pre-split / DMA kernel choices) and at batch 1."""
+    from ddsp.vocoder import CombSub
+    z = np.load(os.path.join(GOLDEN, "model_CombSub_causal.npz"))
+    ref_model, cfg = synthetic.build_model("CombSub", seed=int(z["seed_weights"]))
+    model = CombSub(44100, 512, cfg["n_mag_allpass"], cfg["n_mag_harmonic"], cfg["n_mag_noise"], 256, cfg["n_spk"], c=True)
+    model.load_state_dict(ref_model.state_dict(), strict=True)
+    model = model.to(dev).eval()
+    inp = synthetic.make_inputs(int(z["seed_inputs"]), 2, 24)
+    d = _to(inp, dev)
+    with torch.no_grad():
+        sig, ph, (hm, nz) = model(d["units"], d["f0"], d["volume"], d["spk_id"], noise=d["noise"])
+    want = torch.from_numpy(z["signal"])
+    assert rms(sig.cpu() - want) < GATE, rms(sig.cpu() - want)
+    assert rms(sig.cpu() - want) < 2e-4 * rms(want)
+    ccfg = dict(cfg, c=True)
+    for B, Fr in ((48, 172), (1, 300)):
+        inp = synthetic.make_inputs(950 + B, B, Fr)
+        pick = list(range(0, B, max(1, B // 4)))
+        with torch.no_grad():
+            sig_o = OS.combsub_forward(ref_model.state_dict(), ccfg, inp["units"][pick], inp["f0"][pick], inp["volume"][pick],
+                                       inp["spk_id"][pick], noise=inp["noise"][pick])[0]
+        d = _to(inp, dev)
+        with torch.no_grad():
+            sig = model(d["units"], d["f0"], d["volume"], d["spk_id"], noise=d["noise"])[0]
+        assert rms(sig[pick].cpu() - sig_o) < GATE, (B, Fr, rms(sig[pick].cpu() - sig_o))
+    # training the causal network is not built: it must say so, not silently train the non-causal one
+    model.train()
+    with pytest.raises((NotImplementedError, ValueError)):
+        out = model(d["units"][:1, :8], d["f0"][:1, :8], d["volume"][:1, :8], d["spk_id"][:1], infer=False, noise=d["noise"][:1, :4096])[0]
+        out.sum().backward()

