@@ -5,7 +5,7 @@ loads of the GEMM and the float4 loads of the other kernels are of that kind).""
 import collections, csv, glob, json, sys
 
 def load(d, tag):
-    f = glob.glob(d + "/*/*_counter_collection.csv")[0]
+    f = (glob.glob(d + "/*/*_counter_collection.csv") + glob.glob(d + "/*_counter_collection.csv"))[0]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == tag:
