@@ -63,6 +63,10 @@ struct Args {
     // A is ALREADY in that (8 hi | 8 lo) layout (written so by its producer: LayerNorm, GroupNorm+LeakyReLU, the attention
     // kernel): with math == 3 and B_split the kernel then splits nothing (MATH = 8: bit casts and MFMAs only)
     int A_split;
+    // DMA kernel, one batch: XCD-aware tile order.  Workgroup b runs on XCD b & 7; with xcd != 0 XCD x owns the row blocks
+    // x, x + 8, ... with ALL their column tiles, so the A rows of a row block are fetched into one L2 instead of eight
+    // (the leftover tiles_m % 8 row blocks are dealt round-robin as before).
+    int xcd;
 };
 
 constexpr int BK = 32;
@@ -385,7 +389,22 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ?
     // Persistent workgroup: walks output tiles blockIdx.x, +gridDim.x, ... and treats their k-tiles as ONE stream
     // (step = tile_i*nk + kt), so the DMA of the next tile's first k-tiles is already in flight while the current
     // tile's last MFMAs and its epilogue stores run: no per-tile prologue latency.
-    const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const bool xcd_order = g.xcd && (gridDim.x & 7) == 0 && g.sub_from == 0 && total_tiles == tiles_m * tiles_n;
+    const int xq0 = (int)blockIdx.x >> 3, xgs = (int)gridDim.x >> 3, xx = (int)blockIdx.x & 7;
+    const int xown = (tiles_m / 8) * tiles_n, xleft = (tiles_m % 8) * tiles_n;
+    int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (xcd_order) {
+        const int qx = xown + (xleft > xx ? (xleft - xx + 7) / 8 : 0);
+        my_tiles = xq0 < qx ? (qx - xq0 + xgs - 1) / xgs : 0;
+    }
+    // the i-th tile of this workgroup as a linear id mt * tiles_n + nt
+    auto tile_of = [&](int i) -> int {
+        if (!xcd_order) return (int)blockIdx.x + i * (int)gridDim.x;
+        const int q = xq0 + i * xgs;
+        if (q < xown) return (xx + 8 * (q / tiles_n)) * tiles_n + q % tiles_n;
+        const int u = (q - xown) * 8 + xx;
+        return ((tiles_m / 8) * 8 + u / tiles_n) * tiles_n + u % tiles_n;
+    };
     const int steps = my_tiles * nk;
 
     // per-lane source pointers (k = 0) of this wave's DMA pieces for a given tile; rows past the edge re-read
@@ -459,7 +478,7 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ?
     const float* src_cur[PPW];   // tile that step `issued` belongs to
     int issued = 0;              // next step whose DMA has not been issued yet
     int issue_tile = 0, issue_kt = 0;
-    if (steps > 0) tile_src((int)blockIdx.x, src_cur);
+    if (steps > 0) tile_src(tile_of(0), src_cur);
     auto issue_next = [&]() {
         if (issued >= steps) return;
         if (!(ABLATE & 2)) issue(src_cur, issue_kt, issued % NS);
@@ -467,7 +486,7 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ?
         if (++issue_kt == nk) {
             issue_kt = 0;
             ++issue_tile;
-            if (issue_tile < my_tiles) tile_src((int)blockIdx.x + issue_tile * (int)gridDim.x, src_cur);
+            if (issue_tile < my_tiles) tile_src(tile_of(issue_tile), src_cur);
         }
     };
     issue_next();
@@ -589,7 +608,7 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ?
         }
         if (++kt == nk) {
             // ---- epilogue of this tile (stores drain while the next tile's MFMAs run) ----
-            const int tile = (int)blockIdx.x + tile_i * (int)gridDim.x;
+            const int tile = tile_of(tile_i);
             const int per_z = tiles_m * tiles_n;
             int z = tile / per_z, rem = tile - z * per_z;
             int m0 = (rem / tiles_n) * BM, n0 = (rem % tiles_n) * BN;
@@ -696,8 +715,22 @@ inline void launch_dma(hipStream_t st, const Args& g, int batch, const Epi& epi,
 }
 
 // launch_dma with the product arithmetic chosen at run time (Args::math)
+// XCD-aware tile order: on for the split-bf16 GEMMs, whose loops no longer hide the eightfold A re-reads of the
+// round-robin order (r02: Linear family 0.395 -> 0.373 ms, HBM/fabric traffic of a pw1 call 114 -> ~35 MB); off for fp32
+// products, where round 1 measured it slower (0.76 -> 0.84 ms).  DDSP_GEMM_XCD = 0 / 1 forces it (measurement aid).
+inline int xcd_default(int math) {
+    static int env = -2;
+    if (env == -2) {
+        const char* e = getenv("DDSP_GEMM_XCD");
+        env = e ? (e[0] == '1' ? 1 : 0) : -1;
+    }
+    return env >= 0 ? env : (math == 3 ? 1 : 0);
+}
+
 template <int BM, int BN, class Epi, int NS = 3, int NW = 8, int A_MODE = A_PLAIN>
-inline void dma_go(hipStream_t st, const Args& g, int batch, const Epi& epi, int total_override = -1) {
+inline void dma_go(hipStream_t st, const Args& g0, int batch, const Epi& epi, int total_override = -1) {
+    Args g = g0;
+    if (g.xcd < 0) g.xcd = (batch == 1 && total_override < 0) ? xcd_default(g.math) : 0;
     if (g.math == 3 && g.B_split && g.A_split) {
         Args h = g;
         h.B = g.B_split;
@@ -760,7 +793,7 @@ inline void launch(hipStream_t st, const Args& g, int batch, const Epi& epi) {
                 const int rem = total % 512;
                 bool split = false;
                 if constexpr (!epi_is_gated<Epi>::value) {
-                    if (batch == 1 && rem > 0 && rem <= 64) {
+                    if (batch == 1 && rem > 0 && rem <= 64 && !(g.xcd > 0 || (g.xcd < 0 && xcd_default(g.math)))) {
                         split = true;
                         dma_go<128, 128, Epi, 2>(st, g, batch, epi, total - rem);
                         Args r = g;
@@ -812,6 +845,7 @@ inline Args make(const float* A, int64_t lda, const float* B, int64_t ldb, int M
     g.math = 0;
     g.B_split = nullptr;
     g.A_split = 0;
+    g.xcd = -1;   // decided by dma_go from the product arithmetic (see there)
     return g;
 }
 
