@@ -151,6 +151,20 @@ __device__ __forceinline__ ddsp_u32x4 ddsp_split4_pair(f32x4 v, bool second, int
     return second ? ddsp_u32x4{r0, r1, lo[0], lo[1]} : ddsp_u32x4{hi[0], hi[1], r0, r1};
 }
 
+// The same for EIGHT neighbouring lanes that own one value each (lane j = lane & 7 of the group owns element j): returns
+// the dword this lane must store at ITS OWN element's position - dwords 0..3 of the group are the hi pairs, 4..7 the lo pairs.
+__device__ __forceinline__ uint32_t ddsp_split1_group8(float x, int lane) {
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+    const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v){x, 0.f}, bf16x2v)) & 0xffffu;
+    const float rem = x - __builtin_bit_cast(float, h << 16);
+    const uint32_t l = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v){rem, 0.f}, bf16x2v)) & 0xffffu;
+    const uint32_t pk = h | (l << 16);
+    const int j = lane & 7, src = (lane & ~7) + 2 * (j & 3);
+    const uint32_t a = (uint32_t)__shfl((int)pk, src, 64), b = (uint32_t)__shfl((int)pk, src + 1, 64);
+    return j < 4 ? (a & 0xffffu) | (b << 16) : (a >> 16) | (b & 0xffff0000u);
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

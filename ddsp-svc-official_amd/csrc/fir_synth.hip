@@ -14,8 +14,10 @@ namespace {
 // One wavefront per frame row.  REAL modes: out[f] = exp(ctrl[f]) * scale.
 // ALLPASS: gd = pi*tanh(ctrl); phi = cumsum_f(gd) (fp64 running sum rounded to fp32 per bin, as ATen's
 // CPU cumsum does); out = [cos(phi) | sin(phi)].
+// split != 0: the row is written as bf16 hi/lo groups of 8 (A operand of the split-bf16 inverse-DFT GEMM, gemm A_split);
+// M % 8 == 0 then, and every lane of a group of 8 takes part in the exchange (values past M are zeros).
 __global__ void __launch_bounds__(256) fir_act_kernel(int mode, const float* __restrict__ ctrl, int64_t ld, int M,
-                                                      int ldo, int64_t rows, float* __restrict__ out) {
+                                                      int ldo, int64_t rows, float* __restrict__ out, int split) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -23,6 +25,15 @@ __global__ void __launch_bounds__(256) fir_act_kernel(int mode, const float* __r
     if (mode != DDSP_FIR_ALLPASS) {
         float* dst = out + row * ldo;
         const float scale = (mode == DDSP_FIR_STATIC) ? (1.0f / 128.0f) : 1.0f;
+        if (split) {
+            for (int f0 = 0; f0 < M; f0 += 64) {
+                const int f = f0 + lane;
+                const float v = f < M ? expf(src[f]) * scale : 0.f;
+                const uint32_t w = ddsp_split1_group8(v, lane);
+                if (f < M) ((uint32_t*)dst)[f] = w;
+            }
+            return;
+        }
         for (int f = lane; f < M; f += 64) dst[f] = expf(src[f]) * scale;  // /128 is exact scaling
         return;
     }
@@ -40,9 +51,15 @@ __global__ void __launch_bounds__(256) fir_act_kernel(int mode, const float* __r
         }
         const float phi = (float)(carry + incl);
         carry += __shfl(incl, 63, 64);
-        if (f < M) {
-            double s, c;
-            sincos((double)phi, &s, &c);
+        double s = 0.0, c = 0.0;
+        if (f < M) sincos((double)phi, &s, &c);
+        if (split) {
+            const uint32_t wc = ddsp_split1_group8((float)c, lane), ws = ddsp_split1_group8((float)s, lane);
+            if (f < M) {
+                ((uint32_t*)dst)[f] = wc;
+                ((uint32_t*)dst)[M + f] = ws;
+            }
+        } else if (f < M) {
             dst[f] = (float)c;
             dst[M + f] = (float)s;
         }
@@ -192,9 +209,12 @@ extern "C" int ddsp_fir_from_ctrl(ddsp_ctx* ctx, void* stream, int mode, const f
     float* tab_split = nullptr;   // the same table already split into bf16 hi/lo (B operand of the split-bf16 GEMM)
     if (tap_major && ctx->math != DDSP_MATH_FP32 && (rc = ddsp_get_table(ctx, st, kind, M, 2, &tab_split))) return rc;
 
+    // large row counts with split-bf16 products: the activations are written as bf16 hi/lo groups and the GEMM reads both
+    // operands already split (the DMA kernel is certain at these sizes; B = B_split makes a fallback fail loudly)
+    const bool presplit = tap_major && tab_split && rows >= 8192 && M % 8 == 0 && ctx->math != 4;
     ddsp_prof_begin(ctx, st, PF_FIR_ACT);
     hipLaunchKernelGGL(fir_act_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, mode, ctrl, ctrl_ld, M,
-                       lda, rows, act);
+                       lda, rows, act, presplit ? 1 : 0);
     ddsp_prof_end(ctx, st, 0.0, 4.0 * rows * (M + K));
     DDSP_LAUNCH_CHECK(ctx);
     ddsp_prof_begin(ctx, st, PF_FIR_DFT_GEMM);
@@ -203,6 +223,10 @@ extern "C" int ddsp_fir_from_ctrl(ddsp_ctx* ctx, void* stream, int mode, const f
         // (split-bf16 products like the control network's inference GEMMs: the taps then carry ~4e-6 relative error)
         g.math = tap_major ? (ctx->math == 4 ? DDSP_MATH_SPLIT_BF16 : ctx->math) : 0;   // ddsp_ctx_set_math
         g.B_split = tab_split;
+        if (presplit) {
+            g.A_split = 1;
+            g.B = tab_split;
+        }
         if (tap_major)
             gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, epi);
         else

@@ -335,6 +335,76 @@ __global__ void __launch_bounds__(256) embed_add_kernel(float* __restrict__ x, c
     *(f32x4*)(x + m * D + c) = v;
 }
 
+// The same additions as the epilogue of the second prenet convolution (one launch and one pass over x less): same operation
+// order as embed_add_kernel, so the result is bit-identical.
+struct EpiEmbed {
+    float* out;                 // (rows, 256)
+    const float* bias;          // conv2 bias
+    const float *f0, *phase, *vol;
+    ddsp_u2c_weights w;
+    const int64_t* spk_id;
+    int64_t n_spk_id;
+    MixArgs mix;
+    int Fr;
+    int* err;
+    __device__ __forceinline__ float col(int n) const { return bias[n]; }
+    __device__ __forceinline__ float embed(int m, int n, float v) const {
+        const float lf0 = logf(1.0f + __fdiv_rn(f0[m], 700.0f));
+        const float ph = __fdiv_rn(phase[m], 3.14159274101257324f);
+        v += fmaf(lf0, w.f0_w[n], w.f0_b[n]);
+        v += fmaf(ph, w.phase_w[n], w.phase_b[n]);
+        v += fmaf(vol[m], w.volume_w[n], w.volume_b[n]);
+        if (mix.n > 0) {
+            for (int k = 0; k < mix.n; ++k) v += mix.w[k] * w.spk_table[(mix.ids[k] - 1) * D + n];
+        } else {
+            const int64_t id = spk_id[n_spk_id == 1 ? 0 : m / Fr];
+            if (id >= 1 && id <= w.n_spk)
+                v += w.spk_table[(id - 1) * D + n];
+            else
+                __hip_atomic_store(err, DDSP_DEV_ERR_SPK_ID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return v;
+    }
+    __device__ __forceinline__ void operator()(int, int m, int n, float v, float cb) const {
+        out[(int64_t)m * D + n] = embed(m, n, v + cb);
+    }
+    static constexpr bool kStore4 = true;
+    __device__ __forceinline__ bool vec_ok() const { return ((uintptr_t)out % 16) == 0; }
+    __device__ __forceinline__ void store4(int, int m, int n, f32x4 v) const {
+        typedef gemm::f32x4_u v4;
+        v += *(const v4*)(bias + n);
+        const float lf0 = logf(1.0f + __fdiv_rn(f0[m], 700.0f));
+        const float ph = __fdiv_rn(phase[m], 3.14159274101257324f);
+        const float vl = vol[m];
+        const v4 fw = *(const v4*)(w.f0_w + n), fb = *(const v4*)(w.f0_b + n);
+        const v4 pw = *(const v4*)(w.phase_w + n), pb = *(const v4*)(w.phase_b + n);
+        const v4 vw = *(const v4*)(w.volume_w + n), vb = *(const v4*)(w.volume_b + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] += fmaf(lf0, fw[j], fb[j]);
+            v[j] += fmaf(ph, pw[j], pb[j]);
+            v[j] += fmaf(vl, vw[j], vb[j]);
+        }
+        if (mix.n > 0) {
+            for (int k = 0; k < mix.n; ++k) {
+                const v4 e = *(const v4*)(w.spk_table + (mix.ids[k] - 1) * D + n);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += mix.w[k] * e[j];
+            }
+        } else {
+            const int64_t id = spk_id[n_spk_id == 1 ? 0 : m / Fr];
+            if (id >= 1 && id <= w.n_spk) {
+                const v4 e = *(const v4*)(w.spk_table + (id - 1) * D + n);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += e[j];
+            } else {
+                __hip_atomic_store(err, DDSP_DEV_ERR_SPK_ID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        *(f32x4*)(out + (int64_t)m * D + n) = v;
+    }
+};
+
 // ---- LayerNorm over 256 channels, one wave per row (4 channels per lane) ----------------------------
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int64_t rows,
@@ -525,7 +595,8 @@ template <bool SILU, bool FLIP>
 __global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, int B, int Fr,
                                                      float* __restrict__ out, float* __restrict__ pre, int wsc, int wst,
-                                                     int left) {   // left = DWK / 2: centred taps; DWK - 1: causal taps (frames t-30 .. t)
+                                                     int left, int split) {   // left = DWK / 2: centred taps; DWK - 1: causal taps (frames t-30 .. t)
+    // split != 0 (forward, inference): `out` is written as bf16 hi/lo groups of 8 channels (A operand of the pw2 GEMM)
     const int c = blockIdx.x * 256 + threadIdx.x;       // channel (INNER = 512 -> 2 blocks in x)
     const int runs = (Fr + DW_RUN - 1) / DW_RUN;
     const int b = blockIdx.y / runs, f0 = (blockIdx.y % runs) * DW_RUN;
@@ -549,7 +620,11 @@ __global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ x
             const int64_t idx = ((int64_t)b * Fr + f0 + o) * INNER + c;
             if (SILU) {
                 if (pre) pre[idx] = acc;
-                out[idx] = acc * (1.0f / (1.0f + expf(-acc)));
+                const float y = acc * (1.0f / (1.0f + expf(-acc)));
+                if (split)
+                    ((uint32_t*)out)[idx] = ddsp_split1_group8(y, threadIdx.x & 63);
+                else
+                    out[idx] = y;
             } else {
                 out[idx] = acc;
             }
@@ -1085,7 +1160,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
     // Split-bf16 products at a size where every GEMM of the network runs the LDS-DMA kernel: nothing is split inside the
     // GEMM loops.  The weights are packed as bf16 hi/lo groups by the preparation launch (B_split) and the producers of
     // the A operands (GroupNorm+LeakyReLU, the LayerNorms, the attention kernel) write them in that layout (A_split);
-    // conv1 reads the caller's fp32 units and pw2 the depthwise conv's fp32 output: those two split A in the kernel.
+    // conv1 reads the caller's fp32 units: it alone still splits A in the kernel.
     const bool presplit = lin_math == DDSP_MATH_SPLIT_BF16 && ctx->math != 4 && fuse_glu && M >= 8192 && w.n_unit % 32 == 0 &&
                           w.n_unit + 32 <= DDSP_ZERO_FLOATS && w.n_out >= 256 && ((uintptr_t)in.units % 16) == 0;
     const bool attn_bf16 = !bf.l[0].pre && lin_math == DDSP_MATH_SPLIT_BF16 && B * H >= 256 && !w.causal;
@@ -1155,12 +1230,10 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         g.Fr = (int)Fr;
         g.Cin = D;
         g.zeros = zero_page;
-        gemm::EpiStore e{x, D, w.prenet_conv2_b, 1, 0, 0};
+        // the side embeddings (f0, phase, volume, speaker) are added in this GEMM's epilogue
+        EpiEmbed e{x, w.prenet_conv2_b, in.f0, in.phase, in.volume, w, in.spk_id, in.n_spk_id, in.mix, (int)Fr, dev_err};
         PROF(PF_U2C_GEMM_CONV3, 2.0 * M * D * 3 * D, 8.0 * M * D, (gemm::launch<true, true, gemm::A_CONV3>(st, g, 1, e)));
     }
-    PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
-         hipLaunchKernelGGL(embed_add_kernel, dim3((unsigned)ceil_div64(M, 4)), dim3(256), 0, st, x, in.f0, in.phase, in.volume, w,
-                            in.spk_id, in.n_spk_id, in.mix, M, (int)Fr, dev_err));
     DDSP_LAUNCH_CHECK(ctx);
 
     const unsigned rows_g = (unsigned)ceil_div64(M, 4), rows8_g = (unsigned)ceil_div64(M8, 4);
@@ -1278,10 +1351,10 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         }
         PROF(PF_U2C_ROWWISE, 2.0 * M * INNER * DWK, 8.0 * M * INNER,
              hipLaunchKernelGGL((dwconv_kernel<true, false>), dim3(INNER / 256, (unsigned)(B * ((Fr + DW_RUN - 1) / DW_RUN))),
-                                dim3(256), 0, st, b.glu, bf.wdw + (size_t)l * DWK * INNER, L.cm_dw_b, (int)B, (int)Fr, b.dwo, b.pre, 1, INNER, w.causal ? DWK - 1 : DWK / 2));
+                                dim3(256), 0, st, b.glu, bf.wdw + (size_t)l * DWK * INNER, L.cm_dw_b, (int)B, (int)Fr, b.dwo, b.pre, 1, INNER, w.causal ? DWK - 1 : DWK / 2, asplit));
         {
             gemm::Args g = gemm::make(b.dwo, INNER, L.cm_pw2_w, INNER, iM, D, INNER);
-            set_b(g, bf.wpw2 + (size_t)l * D * INNER, 0);
+            set_b(g, bf.wpw2 + (size_t)l * D * INNER, asplit);
             gemm::EpiResidual e{b.x_out, b.x_mid, D, L.cm_pw2_b};
             PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * D * INNER, 4.0 * M * (INNER + 2 * D),
                  (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
@@ -1514,7 +1587,7 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
                            (int64_t)INNER * DWK, GLP(cm_dw_w));
         if ((rc = colsum(ctx, st, dB512, INNER, M, INNER, nullptr, 0, cpart, GLP(cm_dw_b)))) return rc;
         hipLaunchKernelGGL((dwconv_kernel<false, true>), dim3(INNER / 256, (unsigned)(B * ((Fr + DW_RUN - 1) / DW_RUN))),
-                           dim3(256), 0, st, dB512, L.cm_dw_w, nullptr, (int)B, (int)Fr, dC512, nullptr, DWK, 1, DWK / 2);   // d_glu
+                           dim3(256), 0, st, dB512, L.cm_dw_w, nullptr, (int)B, (int)Fr, dC512, nullptr, DWK, 1, DWK / 2, 0);   // d_glu
         hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for(M * INNER)), dim3(256), 0, st, b.g1, dC512, M, dG1);
         if ((rc = wgrad(ctx, st, dG1, 2 * INNER, 2 * INNER, b.y2, D, D, M, wpart, GLP(cm_pw1_w), D, 0))) return rc;
         if ((rc = colsum(ctx, st, dG1, 2 * INNER, M, 2 * INNER, nullptr, 0, cpart, GLP(cm_pw1_b)))) return rc;
