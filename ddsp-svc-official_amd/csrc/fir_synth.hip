@@ -51,17 +51,19 @@ __global__ void __launch_bounds__(256) fir_act_kernel(int mode, const float* __r
         }
         const float phi = (float)(carry + incl);
         carry += __shfl(incl, 63, 64);
-        double s = 0.0, c = 0.0;
-        if (f < M) sincos((double)phi, &s, &c);
+        // cos / sin of the fp32 phase in fp32, like the reference's complex64 `exp(1j * cumsum)` (the fp64 evaluation used
+        // until round 2 was this kernel's time)
+        float s = 0.f, c = 0.f;
+        if (f < M) sincosf(phi, &s, &c);
         if (split) {
-            const uint32_t wc = ddsp_split1_group8((float)c, lane), ws = ddsp_split1_group8((float)s, lane);
+            const uint32_t wc = ddsp_split1_group8(c, lane), ws = ddsp_split1_group8(s, lane);
             if (f < M) {
                 ((uint32_t*)dst)[f] = wc;
                 ((uint32_t*)dst)[M + f] = ws;
             }
         } else if (f < M) {
-            dst[f] = (float)c;
-            dst[M + f] = (float)s;
+            dst[f] = c;
+            dst[M + f] = s;
         }
     }
 }

@@ -32,7 +32,11 @@ __device__ __forceinline__ double wave_excl_scan_d(double v, int lane) {
 
 template <bool PRECISE>
 __device__ __forceinline__ double increment(float f, float srf, double srd) {
-    if (PRECISE) return (double)f / srd;
+    // precise mode: the reference divides in fp64 (f0.double() / sr); here the fp64 product with 1/sr, which differs from
+    // the quotient by at most one fp64 ulp per sample (~1e-11 cycles over a 2 s clip against the 1e-6 the result is
+    // compared at after the wrap) and costs a multiply instead of a division - the division was this kernel's time
+    // (VALU 1.15 in the round-1 counters).  `srd` carries 1/sr in this mode.
+    if (PRECISE) return (double)f * srd;
     return (double)__fdiv_rn(f, srf);
 }
 
@@ -48,7 +52,7 @@ __global__ void __launch_bounds__(256) frame_sum_kernel(const float* __restrict_
     const float x0 = f0_frames[fidx];
     const float x1 = (m + 1 < Fr) ? f0_frames[fidx + 1] : x0;
     const float srf = (float)sr;
-    const double srd = (double)sr;
+    const double srd = PRECISE ? 1.0 / (double)sr : (double)sr;
     double acc = 0.0;
     const int per_lane = (hop + 63) / 64;
     for (int i = 0; i < per_lane; ++i) {
@@ -89,7 +93,7 @@ __global__ void __launch_bounds__(256) frame_scan_kernel(const float* __restrict
     const float x0 = f0_frames[fidx];
     const float x1 = (m + 1 < Fr) ? f0_frames[fidx + 1] : x0;
     const float srf = (float)sr;
-    const double srd = (double)sr;
+    const double srd = PRECISE ? 1.0 / (double)sr : (double)sr;
 
     // exclusive prefix over the preceding frames of this utterance
     double before = 0.0;
