@@ -764,13 +764,25 @@ inline void launch(hipStream_t st, const Args& g, int batch, const Epi& epi) {
     };
     if constexpr (A_KC && B_KC && A_MODE == A_CONV3) {
         // implicit-im2col convs (N = 256): the 4-wave 64x64 DMA tile with one source pointer per tap
-        if (dma_ok(g) && g.zeros && g.Cin % 32 == 0 && g.Cin + 32 <= DDSP_ZERO_FLOATS && g.N <= 256 &&
-            blocks(64, 64) >= 256) {
+        if (dma_ok(g) && g.zeros && g.Cin % 32 == 0 && g.Cin + 32 <= DDSP_ZERO_FLOATS && g.N <= 256) {
+            // (also for a few tiles: see the small-problem note below)
             dma_go<64, 64, Epi, 3, 4, A_CONV3>(st, g, batch, epi);
             return;
         }
     }
     if constexpr (A_KC && B_KC && A_MODE == A_PLAIN) {
+        // a few tiles and a long K (the 87-frame real-time block: 8 workgroups walking K = 512): the 3-stage DMA ring keeps
+        // two k-tiles in flight, the register-staged kernel's one-tile prefetch leaves a global-load latency per k-tile
+        // exposed (real-time block 0.67 -> 0.50 ms).  DDSP_GEMM_SMALL_DMA=0 restores the old choice (measurement aid).
+        static int small_dma = -1;
+        if (small_dma < 0) {
+            const char* e = getenv("DDSP_GEMM_SMALL_DMA");
+            small_dma = (e && e[0] == '0') ? 0 : 1;
+        }
+        if (small_dma && dma_ok(g) && blocks(64, 64) < 256 && g.K >= 256) {
+            dma_go<64, 64, Epi, 3, 4>(st, g, batch, epi);
+            return;
+        }
         if (dma_ok(g) && g.N <= 256 && blocks(64, 64) >= 256) {
             // skinny layers also at half the bench batch (training, B = 32: 5504 rows -> 344 tiles of 64x64)
             dma_go<64, 64, Epi, 3, 4>(st, g, batch, epi);

@@ -591,28 +591,28 @@ __global__ void __launch_bounds__(256) glu_kernel(const float* __restrict__ g1, 
 constexpr int DW_RUN = 32;
 // SILU: apply SiLU (forward) and optionally keep the pre-activation; FLIP: correlate with reversed taps and no
 // bias (the input-gradient of the same convolution).
-template <bool SILU, bool FLIP>
+template <bool SILU, bool FLIP, int RUN = DW_RUN>
 __global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, int B, int Fr,
                                                      float* __restrict__ out, float* __restrict__ pre, int wsc, int wst,
                                                      int left, int split) {   // left = DWK / 2: centred taps; DWK - 1: causal taps (frames t-30 .. t)
     // split != 0 (forward, inference): `out` is written as bf16 hi/lo groups of 8 channels (A operand of the pw2 GEMM)
     const int c = blockIdx.x * 256 + threadIdx.x;       // channel (INNER = 512 -> 2 blocks in x)
-    const int runs = (Fr + DW_RUN - 1) / DW_RUN;
-    const int b = blockIdx.y / runs, f0 = (blockIdx.y % runs) * DW_RUN;
+    const int runs = (Fr + RUN - 1) / RUN;
+    const int b = blockIdx.y / runs, f0 = (blockIdx.y % runs) * RUN;
     float wt[DWK];
 #pragma unroll
     for (int t = 0; t < DWK; ++t) wt[t] = w[c * wsc + (FLIP ? DWK - 1 - t : t) * wst];
     const float* xb = x + ((int64_t)b * Fr) * INNER + c;
-    float win[DW_RUN + DWK - 1];
+    float win[RUN + DWK - 1];
 #pragma unroll
-    for (int i = 0; i < DW_RUN + DWK - 1; ++i) {
+    for (int i = 0; i < RUN + DWK - 1; ++i) {
         const int f = f0 + i - left;
         win[i] = (f >= 0 && f < Fr) ? xb[(int64_t)f * INNER] : 0.f;
     }
     const float bi = FLIP ? 0.f : bias[c];
 #pragma unroll
-    for (int o = 0; o < DW_RUN; ++o) {
+    for (int o = 0; o < RUN; ++o) {
         float acc = bi;
 #pragma unroll
         for (int t = 0; t < DWK; ++t) acc = fmaf(wt[t], win[o + t], acc);
@@ -1350,8 +1350,12 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
                  hipLaunchKernelGGL(glu_kernel, dim3(grid_for(M * (INNER / 4))), dim3(256), 0, st, b.g1, M, b.glu));
         }
         PROF(PF_U2C_ROWWISE, 2.0 * M * INNER * DWK, 8.0 * M * INNER,
-             hipLaunchKernelGGL((dwconv_kernel<true, false>), dim3(INNER / 256, (unsigned)(B * ((Fr + DW_RUN - 1) / DW_RUN))),
-                                dim3(256), 0, st, b.glu, bf.wdw + (size_t)l * DWK * INNER, L.cm_dw_b, (int)B, (int)Fr, b.dwo, b.pre, 1, INNER, w.causal ? DWK - 1 : DWK / 2, asplit));
+             if (B * ((Fr + DW_RUN - 1) / DW_RUN) >= 64)
+                 hipLaunchKernelGGL((dwconv_kernel<true, false>), dim3(INNER / 256, (unsigned)(B * ((Fr + DW_RUN - 1) / DW_RUN))),
+                                    dim3(256), 0, st, b.glu, bf.wdw + (size_t)l * DWK * INNER, L.cm_dw_b, (int)B, (int)Fr, b.dwo, b.pre, 1, INNER, w.causal ? DWK - 1 : DWK / 2, asplit);
+             else   // a few utterances (the real-time block): runs of 8 frames, four times as many workgroups
+                 hipLaunchKernelGGL((dwconv_kernel<true, false, 8>), dim3(INNER / 256, (unsigned)(B * ((Fr + 7) / 8))),
+                                    dim3(256), 0, st, b.glu, bf.wdw + (size_t)l * DWK * INNER, L.cm_dw_b, (int)B, (int)Fr, b.dwo, b.pre, 1, INNER, w.causal ? DWK - 1 : DWK / 2, asplit));
         {
             gemm::Args g = gemm::make(b.dwo, INNER, L.cm_pw2_w, INNER, iM, D, INNER);
             set_b(g, bf.wpw2 + (size_t)l * D * INNER, asplit);

@@ -148,9 +148,17 @@ class _SynthTrainFn(torch.autograd.Function):
     def forward(fctx, model, units, f0_frames, volume, spk_id, spk_mix_dict, initial_phase, infer, noise, noise_seed,
                 *params):
         ctx, ps = model._front(f0_frames, initial_phase, infer, model._comb_mode, **model._front_wants)
-        ctrl = model.unit2ctrl.forward_flat(units, f0_frames, ps["phase_frames"], volume, spk_id, spk_mix_dict)
-        nargs = model._noise_args(noise, noise_seed)
-        outs, saved = model._train_forward(ctx, ctrl, ps, f0_frames, nargs)
+        # the training forward runs fp32 products throughout (control network, filter synthesis, FIR): the backward call
+        # re-runs the control network in fp32 to rebuild its activations and the adjoints multiply in fp32, and the loss
+        # gradient amplifies a 4e-6 disagreement between the two passes a thousandfold (tools/diag_train_b32.py)
+        keep_math = ctx.math
+        ctx.set_math(hipddsp.MATH_FP32)
+        try:
+            ctrl = model.unit2ctrl.forward_flat(units, f0_frames, ps["phase_frames"], volume, spk_id, spk_mix_dict)
+            nargs = model._noise_args(noise, noise_seed)
+            outs, saved = model._train_forward(ctx, ctrl, ps, f0_frames, nargs)
+        finally:
+            ctx.set_math(keep_math)
         fctx.model, fctx.dsp = model, ctx
         fctx.args = (units, f0_frames, volume, spk_id, spk_mix_dict, nargs, ps["phase_frames"])
         fctx.saved = (ctrl, saved)

@@ -48,8 +48,9 @@ int ddsp_ctx_poll_error(ddsp_ctx* ctx);
  *   DDSP_MATH_SPLIT_BF16 (default): every fp32 product from three bf16 matrix products (hi*hi + hi*lo + lo*hi), fp32
  *                         accumulation, ~4e-6 relative error per contraction - narrower than the reference's fp32;
  *   DDSP_MATH_FP32:       fp32 matrix products (v_mfma_f32_*_f32), ~3e-7 - the reference's precision class.
- * Training (ddsp_unit2ctrl_bwd and every *_bwd entry point) always uses fp32 products.  Small problems that do not
- * reach the LDS-DMA GEMM kernel run fp32 products in either mode. */
+ * Training (ddsp_unit2ctrl_bwd and every *_bwd entry point) always uses fp32 products; the Python mirror also runs the
+ * control network's training FORWARD in fp32 (the backward call rebuilds its activations in fp32).  GEMMs whose shape
+ * keeps them off the LDS-DMA kernel (K not a multiple of 32, unaligned rows) run fp32 products in either mode. */
 #define DDSP_MATH_FP32 0
 #define DDSP_MATH_SPLIT_BF16 3
 int ddsp_ctx_set_math(ddsp_ctx* ctx, int math);
