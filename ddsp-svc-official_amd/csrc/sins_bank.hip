@@ -34,6 +34,47 @@ __global__ void __launch_bounds__(256) sins_bank_kernel(const float* __restrict_
     const float* a0 = amp;
     const float* a1 = amp + H;
     const float inv_hop = 1.0f / (float)hop;  // hop is a power of two: exact
+    if (hop == 2 * (int)blockDim.x && (H & 3) == 0) {
+        // hop = 512: a thread owns samples j and j + 256 and walks the harmonics for both at once in packed fp32
+        // (v_pk_fma_f32 / v_pk_mul_f32: two samples per instruction), with the window taken out of the harmonic sum:
+        //   sum_k (w0 A0_k + w1 A1_k) sin_k = w0 sum_k A0_k sin_k + w1 sum_k A1_k sin_k,
+        // so a harmonic costs 6 packed instructions for two samples (3 per sample instead of 7) and its two amplitudes are
+        // read from the LDS once for both samples, four harmonics per 16-byte read.
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const int j = threadIdx.x;
+        const int64_t t = row * hop + j;
+        const f32x2 ph = {phase[t], phase[t + blockDim.x]};
+        float sa, ca, sb, cb;
+        sincosf(ph[0], &sa, &ca);
+        sincosf(ph[1], &sb, &cb);
+        const f32x2 s1 = {sa, sb}, c1 = {ca, cb};
+        f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+        for (int k0 = 0; k0 < H; k0 += RESEED) {
+            // seed at harmonic k0+1 with the reference's own argument rounding: sin(fp32((k0+1) * ph))
+            sincosf(__fmul_rn(ph[0], (float)(k0 + 1)), &sa, &ca);
+            sincosf(__fmul_rn(ph[1], (float)(k0 + 1)), &sb, &cb);
+            f32x2 zs = {sa, sb}, zc = {ca, cb};
+            const int kend = (k0 + RESEED < H) ? k0 + RESEED : H;
+            for (int k = k0; k < kend; k += 4) {
+                const f32x4 A0 = *(const f32x4*)(a0 + k), A1 = *(const f32x4*)(a1 + k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc0 = __builtin_elementwise_fma((f32x2){A0[e], A0[e]}, zs, acc0);
+                    acc1 = __builtin_elementwise_fma((f32x2){A1[e], A1[e]}, zs, acc1);
+                    const f32x2 nc = __builtin_elementwise_fma(zc, c1, -(zs * s1));
+                    const f32x2 ns = __builtin_elementwise_fma(zs, c1, zc * s1);
+                    zc = nc;
+                    zs = ns;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float w1 = (float)(j + i * (int)blockDim.x) * inv_hop, w0 = 1.0f - w1;
+            out[t + i * blockDim.x] = fmaf(w0, acc0[i], w1 * acc1[i]);
+        }
+        return;
+    }
     for (int j = threadIdx.x; j < hop; j += blockDim.x) {
         const int64_t t = row * hop + j;
         const float ph = phase[t];
