@@ -223,7 +223,7 @@ def main():
         crit = RSSLoss(256, 2048, 4, device=dev)
         sg = torch.Generator().manual_seed(1234)      # the same n_fft draws on every rank
         gather = None
-        bucket = training.GradBucket(model.parameters())   # every .grad a view of one flat buffer: one all_reduce per step
+        bucket = training.GradBucket(model.parameters(), model)   # every .grad a view of one flat buffer: one all_reduce per step
 
         def step(i):
             scales = [int(v) for v in torch.randint(256, 2048, (4,), generator=sg)]

@@ -820,6 +820,11 @@ inline void launch(hipStream_t st, const Args& g, int batch, const Epi& epi) {
                 dma_go<128, 64, Epi, 3>(st, g, batch, epi);
             return;
         }
+        if (dma_ok(g) && blocks(64, 64) >= 256) {
+            // the sizes between the small-problem rule and the 128-row tilings (N > 256 at 2-4 k rows)
+            dma_go<64, 64, Epi, 3, 4>(st, g, batch, epi);
+            return;
+        }
     }
     if ((g.B_split && g.B_split == g.B) || g.A_split) {
         // operands that exist ONLY pre-split can be read by the DMA kernel alone (a caller that also has the fp32 matrix passes

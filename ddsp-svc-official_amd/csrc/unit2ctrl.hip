@@ -11,6 +11,7 @@
 // row-wise exp pass.  Everything else (GroupNorm, LayerNorm, GLU, depthwise k=31 conv + SiLU, embeddings,
 // weight-norm) is small fused elementwise / row-reduction kernels.
 #include "gemm_f32.h"
+#include "wgrad_bf16.h"
 #include "performer_attn.h"
 
 namespace {
@@ -681,7 +682,51 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
 
 // Column sums over rows, optionally weighted per row: out_partial[chunk][c] = sum_{r in chunk} X[r][c] * w(r).
 // wmode: 0 none, 1 w = wsrc[r], 2 w = ln(1 + wsrc[r]/700), 3 w = wsrc[r]/pi     (the three side embeddings)
-constexpr int CS_CHUNKS = 32;
+constexpr int CS_CHUNKS = 128;
+// 16 bytes per lane (4 columns), four row lanes per block, two independent accumulators per lane: the variant for
+// 16-byte-aligned matrices whose width is a multiple of 4 (every caller but the odd-width heads).  Round 2: the scalar
+// kernel below ran at 0.9 TB/s (13 us for an 11 MB matrix, 54 launches per training step).
+__global__ void __launch_bounds__(256) colsum_partial_v4_kernel(const float* __restrict__ X, int64_t ld, int64_t rows,
+                                                                int cols, const float* __restrict__ wsrc, int wmode,
+                                                                float* __restrict__ partial) {
+    const int c = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int rl = threadIdx.x >> 6;
+    const int64_t per = (rows + CS_CHUNKS - 1) / CS_CHUNKS;
+    const int64_t r0 = (int64_t)blockIdx.y * per;
+    int64_t r1 = r0 + per;
+    if (r1 > rows) r1 = rows;
+    auto weight = [&](int64_t r) -> float {
+        if (wmode == 1) return wsrc[r];
+        if (wmode == 2) return logf(1.0f + __fdiv_rn(wsrc[r], 700.0f));
+        if (wmode == 3) return __fdiv_rn(wsrc[r], 3.14159274101257324f);
+        return 1.0f;
+    };
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    if (c < cols) {
+        int64_t r = r0 + rl;
+        for (; r + 4 < r1; r += 8) {
+            const f32x4 a = *(const f32x4*)(X + r * ld + c), b = *(const f32x4*)(X + (r + 4) * ld + c);
+            const float wa = weight(r), wb = weight(r + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s0[j] = fmaf(a[j], wa, s0[j]);
+                s1[j] = fmaf(b[j], wb, s1[j]);
+            }
+        }
+        if (r < r1) {
+            const f32x4 a = *(const f32x4*)(X + r * ld + c);
+            const float wa = weight(r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s0[j] = fmaf(a[j], wa, s0[j]);
+        }
+    }
+    __shared__ f32x4 red[256];
+    red[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (rl == 0 && c < cols)
+        *(f32x4*)(partial + (int64_t)blockIdx.y * cols + c) =
+            (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+}
 __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ X, int64_t ld, int64_t rows,
                                                              int cols, const float* __restrict__ wsrc, int wmode,
                                                              float* __restrict__ partial) {
@@ -710,20 +755,27 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __rest
 }
 
 // out[i] = sum_{z < nz} partial[z][i]  (also the split-K reduction of the weight-gradient GEMMs)
+// block = 64 elements x 4 z-lanes (launch with 256 threads, ceil(n / 64) blocks): a thread adds every fourth partial in
+// two chains, the lanes meet in the LDS.  (One thread per element walked 128 partials alone: 10.5 us per call, 47 calls
+// per training step.)
 __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __restrict__ partial, int nz, int64_t n,
                                                               float* __restrict__ out) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four independent chains keep the loads in flight
-        int z = 0;
-        for (; z + 3 < nz; z += 4) {
+    const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int zl = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < n) {
+        int z = zl;
+        for (; z + 4 < nz; z += 8) {
             s0 += partial[(int64_t)z * n + i];
-            s1 += partial[(int64_t)(z + 1) * n + i];
-            s2 += partial[(int64_t)(z + 2) * n + i];
-            s3 += partial[(int64_t)(z + 3) * n + i];
+            s1 += partial[(int64_t)(z + 4) * n + i];
         }
-        for (; z < nz; ++z) s0 += partial[(int64_t)z * n + i];
-        out[i] = (s0 + s1) + (s2 + s3);
+        if (z < nz) s0 += partial[(int64_t)z * n + i];
     }
+    __shared__ float red[256];
+    red[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (zl == 0 && i < n)
+        out[i] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
 }
 
 __global__ void __launch_bounds__(256) silu_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ dout,
@@ -895,6 +947,12 @@ struct EpiAccumulate {  // C += acc
     int64_t ldc;
     __device__ __forceinline__ float col(int) const { return 0.f; }
     __device__ __forceinline__ void operator()(int, int m, int n, float v, float) const { C[(int64_t)m * ldc + n] += v; }
+    static constexpr bool kStore4 = true;
+    __device__ __forceinline__ bool vec_ok() const { return ((uintptr_t)C % 16) == 0 && ldc % 4 == 0; }
+    __device__ __forceinline__ void store4(int, int m, int n, f32x4 v) const {
+        f32x4* p = (f32x4*)(C + (int64_t)m * ldc + n);
+        *p = *p + v;
+    }
 };
 
 // GroupNorm(4) + LeakyReLU backward.  Pass 1 (per utterance, group): s1 = sum dy*g, s2 = sum dy*g*xhat over 64 ch x Fr.
@@ -1452,16 +1510,96 @@ static int wgrad(ddsp_ctx* ctx, hipStream_t st, const float* dY, int64_t ldy, in
 // out[c] = sum_r X[r][c] * w(r)
 static int colsum(ddsp_ctx* ctx, hipStream_t st, const float* X, int64_t ld, int64_t rows, int cols, const float* wsrc,
                   int wmode, float* partial, float* out) {
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, CS_CHUNKS), dim3(256), 0, st, X, ld, rows, cols, wsrc,
-                       wmode, partial);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(cols, 64)), dim3(64), 0, st, partial, CS_CHUNKS, (int64_t)cols, out);
+    if (cols % 4 == 0 && ld % 4 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)partial % 16) == 0)
+        hipLaunchKernelGGL(colsum_partial_v4_kernel, dim3((cols + 255) / 256, CS_CHUNKS), dim3(256), 0, st, X, ld, rows, cols,
+                           wsrc, wmode, partial);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, CS_CHUNKS), dim3(256), 0, st, X, ld, rows, cols, wsrc,
+                           wmode, partial);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, partial, CS_CHUNKS, (int64_t)cols, out);
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}
+
+// Weight and bias gradient of one Linear (taps = 1) or Conv1d k=3 (taps = 3, X = the layer's input, out = the packed
+// (O, 3*C) matrix) from the same dY.  With split-bf16 products (the context's default arithmetic) one launch of the
+// transposing bf16 kernel (wgrad_bf16.h) produces the split partials of both and two small kernels add them; with
+// ddsp_ctx_set_math(FP32) the round-1 path runs: fp32-MFMA split-K batches, shifted copies of X per tap, a separate column sum.
+static int wgrad_tile_choice() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("DDSP_WGRAD_TILE");   // measurement aid: 11, 21, 12, 22 = (TM, TN)
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+static int layer_grads(ddsp_ctx* ctx, hipStream_t st, const float* dY, int64_t ldy, int O, const float* X, int64_t ldx, int C,
+                       int taps, int Fr, int64_t M, float* wpart, float* cpart, float* xs, float* w_out, int64_t ldo,
+                       float* b_out) {
+    int rc;
+    const bool split = ctx->math == DDSP_MATH_SPLIT_BF16 && (taps == 1 || C % 128 == 0);
+    if (!split) {
+        if (taps == 1) {
+            if ((rc = wgrad(ctx, st, dY, ldy, O, X, ldx, C, M, wpart, w_out, ldo, 0))) return rc;
+        } else {
+            for (int tap = 0; tap < taps; ++tap) {
+                hipLaunchKernelGGL(shift_rows_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, st, X, M, Fr, C, tap - 1, xs);
+                if ((rc = wgrad(ctx, st, dY, ldy, O, xs, C, C, M, wpart, w_out, ldo, tap * C))) return rc;
+            }
+        }
+        if (b_out) return colsum(ctx, st, dY, ldy, M, O, nullptr, 0, cpart, b_out);
+        return DDSP_OK;
+    }
+    wgrad::Args g;
+    g.dY = dY;
+    g.ldy = ldy;
+    g.O = O;
+    g.X = X;
+    g.ldx = ldx;
+    g.C = C;
+    g.taps = taps;
+    g.Fr = Fr;
+    g.M = M;
+    g.chunk = wgrad::chunk_for(M, WG_SPLITS);
+    g.partial = wpart;
+    g.bias_partial = b_out ? cpart : nullptr;
+    const int nz = wgrad::splits_for(M, g.chunk), N = taps * C;
+    ddsp_prof_begin(ctx, st, PF_U2C_BWD);
+    int tile = wgrad_tile_choice();
+    // 64x64 tiles: with 16 splits every layer of the network gives 512-1280 workgroups; the larger tiles stage less per
+    // product but leave CUs idle at these sizes (r02, training step B=32: 8.30 ms against 8.45 / 8.45 / 8.59 with 128x64 /
+    // 64x128 / 128x128)
+    if (tile == 0) tile = 11;
+    if (tile == 22) wgrad::launch<2, 2>(st, g);
+    else if (tile == 21) wgrad::launch<2, 1>(st, g);
+    else if (tile == 12) wgrad::launch<1, 2>(st, g);
+    else wgrad::launch<1, 1>(st, g);
+    hipLaunchKernelGGL(reduce_partials_2d_kernel, dim3(grid_for((int64_t)O * N)), dim3(256), 0, st, wpart, nz, O, N, w_out, ldo, 0);
+    if (b_out) hipLaunchKernelGGL(reduce_partials_kernel, dim3((O + 63) / 64), dim3(256), 0, st, cpart, nz, (int64_t)O, b_out);
+    ddsp_prof_end(ctx, st, 2.0 * M * O * (double)N, 4.0 * M * (O + C));
     DDSP_LAUNCH_CHECK(ctx);
     return DDSP_OK;
 }
 
 // dX[m][c] = sum_o dY[m][o] * W[o][c]   (W stored (O, C) like nn.Linear.weight), optionally accumulated into dX
+// WT: the weight transposed to (C, O) in the pre-split operand layout (transpose_split_kernel), or null.  With it the
+// product runs on the LDS-DMA kernel in split-bf16 arithmetic (dY split in the loop, W read split); without it on the
+// register-staged fp32 kernel, which can read W as stored.
 static void dgrad(hipStream_t st, const float* dY, int64_t ldy, const float* W, int O, int C, int64_t M, float* dX,
-                  bool accumulate) {
+                  bool accumulate, const float* WT = nullptr) {
+    if (WT) {
+        gemm::Args g = gemm::make(dY, ldy, WT, O, (int)M, C, O);
+        g.math = DDSP_MATH_SPLIT_BF16;
+        g.B_split = WT;
+        if (accumulate) {
+            EpiAccumulate e{dX, C};
+            gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e);
+        } else {
+            gemm::EpiStore e{dX, C, nullptr, 1, 0, 0};
+            gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e);
+        }
+        return;
+    }
     gemm::Args g = gemm::make(dY, ldy, W, C, (int)M, C, O);
     if (accumulate) {
         EpiAccumulate e{dX, C};
@@ -1469,6 +1607,35 @@ static void dgrad(hipStream_t st, const float* dY, int64_t ldy, const float* W, 
     } else {
         gemm::EpiStore e{dX, C, nullptr, 1, 0, 0};
         gemm::launch<true, false, gemm::A_PLAIN>(st, g, 1, e);
+    }
+}
+
+// Transposed, pre-split copies of the weights the input gradients multiply by: dst[c][o] (pitch O) in the (8 hi | 8 lo)
+// group layout of gemm::Args::B_split.  One launch for all matrices of the network (blockIdx.y = matrix); a thread owns
+// one (column c, group of 8 rows o) record, like the staging of wgrad_bf16.h.
+constexpr int TS_MAX = 20;
+struct TsArgs {
+    const float* src[TS_MAX];
+    float* dst[TS_MAX];
+    int O[TS_MAX], C[TS_MAX];
+};
+__global__ void __launch_bounds__(256) transpose_split_kernel(TsArgs t) {
+    const int mi = blockIdx.y;
+    const float* __restrict__ src = t.src[mi];
+    float* __restrict__ dst = t.dst[mi];
+    const int O = t.O[mi], C = t.C[mi];
+    const int tiles_c = C / 64, tiles = tiles_c * (O / 32);
+    const int c_in = threadIdx.x & 63, og = threadIdx.x >> 6;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int c = (tile % tiles_c) * 64 + c_in, o = (tile / tiles_c) * 32 + og * 8;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = src[(int64_t)(o + j) * C + c];
+        ddsp_u32x4 hi, lo;
+        ddsp_split8(x, hi, lo);
+        ddsp_u32x4* p = reinterpret_cast<ddsp_u32x4*>(dst + (int64_t)c * O + o);
+        p[0] = hi;
+        p[1] = lo;
     }
 }
 
@@ -1524,7 +1691,7 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
     // ---- arena: kept forward activations + backward temporaries ----
     U2CBufs bf;
     float *ctrl, *dX, *dA, *dB512, *dC512, *dV512, *dG1, *dQF, *dKF, *dcx, *dks, *dD, *coefq, *coefk, *gx, *wpart, *cpart,
-        *dWh, *pk, *xs, *dwpart, *gbst, *w2t;
+        *dWh, *pk, *xs, *dwpart, *gbst, *w2t, *wts;
     auto plan_bwd = [&](Arena& a) {
         plan_forward(a, bf, w, B, Fr, true);
         ctrl = a.get((size_t)M * NO);
@@ -1551,6 +1718,7 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
         dwpart = a.get((size_t)B * DWG_CHUNKS * INNER * DWK);
         gbst = a.get((size_t)B * 4 * 2);
         w2t = a.get((size_t)D * 3 * D);
+        wts = a.get((size_t)NO * D + 3 * ((size_t)2 * D * INNER + (size_t)2 * INNER * D + (size_t)3 * INNER * D));
     };
     Arena dry{ctx, true, 0, 0};
     plan_bwd(dry);
@@ -1566,12 +1734,39 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
     if (ctrl_out) DDSP_HIP(ctx, hipMemcpyAsync(ctrl_out, ctrl, (size_t)M * NO * sizeof(float), hipMemcpyDeviceToDevice, st));
 
     const unsigned rows_g = (unsigned)ceil_div64(M, 4), rows8_g = (unsigned)ceil_div64(M8, 4);
+    // ---- transposed split copies of the weights for the input-gradient products (split-bf16 arithmetic only) ----
+    const float *wt_head = nullptr, *wt_pw2[3] = {}, *wt_pw1[3] = {}, *wt_out[3] = {}, *wt_qkv[3][3] = {};
+    if (ctx->math == DDSP_MATH_SPLIT_BF16) {
+        TsArgs ts;
+        int n = 0;
+        float* next = wts;
+        auto add = [&](const float* src, int O, int C) -> const float* {
+            if (O % 32 != 0 || C % 64 != 0 || O < 256) return nullptr;   // (gemm::launch sends K >= 256 to the DMA kernel at every M)
+            ts.src[n] = src;
+            ts.dst[n] = next;
+            ts.O[n] = O;
+            ts.C[n] = C;
+            ++n;
+            next += (size_t)O * C;
+            return next - (size_t)O * C;
+        };
+        wt_head = add(bf.wh, NO, D);
+        for (int l = 0; l < 3; ++l) {
+            wt_pw2[l] = add(w.layer[l].cm_pw2_w, D, INNER);
+            wt_pw1[l] = add(w.layer[l].cm_pw1_w, 2 * INNER, D);
+            wt_out[l] = add(w.layer[l].out_w, D, INNER);
+            wt_qkv[l][0] = add(w.layer[l].q_w, INNER, D);
+            wt_qkv[l][1] = add(w.layer[l].k_w, INNER, D);
+            wt_qkv[l][2] = add(w.layer[l].v_w, INNER, D);
+        }
+        static_assert(TS_MAX >= 19, "table too small");
+        hipLaunchKernelGGL(transpose_split_kernel, dim3(64, n), dim3(256), 0, st, ts);
+    }
     // ---- head: ctrl = LN(x) W^T + b, W = g v/|v| ----
-    if ((rc = wgrad(ctx, st, d_ctrl, NO, NO, bf.y_final, D, D, M, wpart, dWh, D, 0))) return rc;
+    if ((rc = layer_grads(ctx, st, d_ctrl, NO, NO, bf.y_final, D, D, 1, (int)Fr, M, wpart, cpart, xs, dWh, D, G(head_b)))) return rc;
     hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((NO + 3) / 4), dim3(256), 0, st, w.head_g, w.head_v, dWh, NO, D,
                        G(head_g), G(head_v));
-    if ((rc = colsum(ctx, st, d_ctrl, NO, M, NO, nullptr, 0, cpart, G(head_b)))) return rc;
-    dgrad(st, d_ctrl, NO, bf.wh, NO, D, M, dA, false);
+    dgrad(st, d_ctrl, NO, bf.wh, NO, D, M, dA, false, wt_head);
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(rows_g), dim3(256), 0, st, bf.l[2].x_out, w.final_ln_w, dA, nullptr, M, dX, gx);
     if ((rc = colsum(ctx, st, gx, D, M, D, nullptr, 0, cpart, G(final_ln_w)))) return rc;
     if ((rc = colsum(ctx, st, dA, D, M, D, nullptr, 0, cpart, G(final_ln_b)))) return rc;
@@ -1582,29 +1777,29 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
         LayerBufs& b = bf.l[l];
 #define GLP(p) const_cast<float*>(GL.p)
         // ===== conv module: x_out = x_mid + pw2(silu(dw(glu(pw1(LN(x_mid)))))) =====
-        if ((rc = wgrad(ctx, st, dX, D, D, b.dwo, INNER, INNER, M, wpart, GLP(cm_pw2_w), INNER, 0))) return rc;
-        if ((rc = colsum(ctx, st, dX, D, M, D, nullptr, 0, cpart, GLP(cm_pw2_b)))) return rc;
-        dgrad(st, dX, D, L.cm_pw2_w, D, INNER, M, dB512, false);                                   // d_dwo
+        if ((rc = layer_grads(ctx, st, dX, D, D, b.dwo, INNER, INNER, 1, (int)Fr, M, wpart, cpart, xs, GLP(cm_pw2_w), INNER,
+                              GLP(cm_pw2_b)))) return rc;
+        dgrad(st, dX, D, L.cm_pw2_w, D, INNER, M, dB512, false, wt_pw2[l]);                                  // d_dwo
         hipLaunchKernelGGL(silu_bwd_kernel, dim3(grid_for(M * INNER)), dim3(256), 0, st, b.pre, dB512, M * INNER, dB512);  // d_pre
         hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(INNER / 64, (unsigned)B, DWG_CHUNKS), dim3(256), 0, st, dB512, b.glu, (int)Fr, dwpart);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(INNER * DWK)), dim3(256), 0, st, dwpart, (int)B * DWG_CHUNKS,
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((INNER * DWK + 63) / 64), dim3(256), 0, st, dwpart, (int)B * DWG_CHUNKS,
                            (int64_t)INNER * DWK, GLP(cm_dw_w));
         if ((rc = colsum(ctx, st, dB512, INNER, M, INNER, nullptr, 0, cpart, GLP(cm_dw_b)))) return rc;
         hipLaunchKernelGGL((dwconv_kernel<false, true>), dim3(INNER / 256, (unsigned)(B * ((Fr + DW_RUN - 1) / DW_RUN))),
                            dim3(256), 0, st, dB512, L.cm_dw_w, nullptr, (int)B, (int)Fr, dC512, nullptr, DWK, 1, DWK / 2, 0);   // d_glu
         hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for(M * INNER)), dim3(256), 0, st, b.g1, dC512, M, dG1);
-        if ((rc = wgrad(ctx, st, dG1, 2 * INNER, 2 * INNER, b.y2, D, D, M, wpart, GLP(cm_pw1_w), D, 0))) return rc;
-        if ((rc = colsum(ctx, st, dG1, 2 * INNER, M, 2 * INNER, nullptr, 0, cpart, GLP(cm_pw1_b)))) return rc;
-        dgrad(st, dG1, 2 * INNER, L.cm_pw1_w, 2 * INNER, D, M, dA, false);                         // d_y2
+        if ((rc = layer_grads(ctx, st, dG1, 2 * INNER, 2 * INNER, b.y2, D, D, 1, (int)Fr, M, wpart, cpart, xs, GLP(cm_pw1_w), D,
+                              GLP(cm_pw1_b)))) return rc;
+        dgrad(st, dG1, 2 * INNER, L.cm_pw1_w, 2 * INNER, D, M, dA, false, wt_pw1[l]);                         // d_y2
         hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(rows_g), dim3(256), 0, st, b.x_mid, L.cm_ln_w, dA, dX, M, dX, gx);
         if ((rc = colsum(ctx, st, gx, D, M, D, nullptr, 0, cpart, GLP(cm_ln_w)))) return rc;
         if ((rc = colsum(ctx, st, dA, D, M, D, nullptr, 0, cpart, GLP(cm_ln_b)))) return rc;
         // dX now holds d x_mid
 
         // ===== attention: x_mid = x_in + to_out(attn) =====
-        if ((rc = wgrad(ctx, st, dX, D, D, b.attn, INNER, INNER, M, wpart, GLP(out_w), INNER, 0))) return rc;
-        if ((rc = colsum(ctx, st, dX, D, M, D, nullptr, 0, cpart, GLP(out_b)))) return rc;
-        dgrad(st, dX, D, L.out_w, D, INNER, M, dB512, false);                                       // d_attn
+        if ((rc = layer_grads(ctx, st, dX, D, D, b.attn, INNER, INNER, 1, (int)Fr, M, wpart, cpart, xs, GLP(out_w), INNER,
+                              GLP(out_b)))) return rc;
+        dgrad(st, dX, D, L.out_w, D, INNER, M, dB512, false, wt_out[l]);                                       // d_attn
         hipLaunchKernelGGL(attn_out_bwd_kernel, dim3(rows8_g), dim3(256), 0, st, dB512, b.attn, b.dinv, M8, dD);  // d_num, d_D
         {   // d_q' = d_num ctx^T + d_D ks^T
             gemm::Args g = gemm::make(dB512, INNER, b.cx, DH, (int)Fr, NF, DH);
@@ -1663,9 +1858,8 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
         float* gw[3] = {GLP(q_w), GLP(k_w), GLP(v_w)};
         float* gb[3] = {GLP(q_b), GLP(k_b), GLP(v_b)};
         for (int i = 0; i < 3; ++i) {
-            if ((rc = wgrad(ctx, st, dqkv[i], INNER, INNER, b.y, D, D, M, wpart, gw[i], D, 0))) return rc;
-            if ((rc = colsum(ctx, st, dqkv[i], INNER, M, INNER, nullptr, 0, cpart, gb[i]))) return rc;
-            dgrad(st, dqkv[i], INNER, pw[i], INNER, D, M, dA, i > 0);                               // d_y (summed)
+            if ((rc = layer_grads(ctx, st, dqkv[i], INNER, INNER, b.y, D, D, 1, (int)Fr, M, wpart, cpart, xs, gw[i], D, gb[i]))) return rc;
+            dgrad(st, dqkv[i], INNER, pw[i], INNER, D, M, dA, i > 0, wt_qkv[l][i]);                               // d_y (summed)
         }
         hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(rows_g), dim3(256), 0, st, b.x_in, L.norm_w, dA, dX, M, dX, gx);
         if ((rc = colsum(ctx, st, gx, D, M, D, nullptr, 0, cpart, GLP(norm_w)))) return rc;
@@ -1684,12 +1878,8 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
     DDSP_HIP(ctx, hipMemsetAsync(G(spk_table), 0, (size_t)w.n_spk * D * sizeof(float), st));
     hipLaunchKernelGGL(spk_embed_bwd_kernel, dim3((unsigned)B), dim3(D), 0, st, dX, B, (int)Fr, in.spk_id, in.n_spk_id,
                        in.mix, G(spk_table), w.n_spk);
-    if ((rc = colsum(ctx, st, dX, D, M, D, nullptr, 0, cpart, G(prenet_conv2_b)))) return rc;
-    // ---- prenet conv2: weight gradient by taps (shifted copies of its input), input gradient as the flipped conv ----
-    for (int tap = 0; tap < 3; ++tap) {
-        hipLaunchKernelGGL(shift_rows_kernel, dim3(grid_for(M * (D / 4))), dim3(256), 0, st, bf.t2, M, (int)Fr, D, tap - 1, xs);
-        if ((rc = wgrad(ctx, st, dX, D, D, xs, D, D, M, wpart, pk, 3 * D, tap * D))) return rc;
-    }
+    // ---- prenet conv2: weight gradient over the three taps, input gradient as the flipped conv ----
+    if ((rc = layer_grads(ctx, st, dX, D, D, bf.t2, D, D, 3, (int)Fr, M, wpart, cpart, xs, pk, 3 * D, G(prenet_conv2_b)))) return rc;
     hipLaunchKernelGGL(unpack_conv3_kernel, dim3(grid_for((int64_t)D * D * 3)), dim3(256), 0, st, pk, D, D, G(prenet_conv2_w));
     hipLaunchKernelGGL(pack_conv3_transposed_kernel, dim3(grid_for((int64_t)D * D * 3)), dim3(256), 0, st, w.prenet_conv2_w, D, D, w2t);
     {
@@ -1708,12 +1898,8 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
     if ((rc = colsum(ctx, st, gx, D, M, D, nullptr, 0, cpart, G(prenet_gn_w)))) return rc;
     if ((rc = colsum(ctx, st, dA, D, M, D, nullptr, 0, cpart, G(prenet_gn_b)))) return rc;
     // ---- prenet conv1 (the units carry no gradient) ----
-    if ((rc = colsum(ctx, st, dX, D, M, D, nullptr, 0, cpart, G(prenet_conv1_b)))) return rc;
-    for (int tap = 0; tap < 3; ++tap) {
-        hipLaunchKernelGGL(shift_rows_kernel, dim3(grid_for(M * (w.n_unit / 4))), dim3(256), 0, st, in.units, M, (int)Fr,
-                           w.n_unit, tap - 1, xs);
-        if ((rc = wgrad(ctx, st, dX, D, D, xs, w.n_unit, w.n_unit, M, wpart, pk, 3 * w.n_unit, tap * w.n_unit))) return rc;
-    }
+    if ((rc = layer_grads(ctx, st, dX, D, D, in.units, w.n_unit, w.n_unit, 3, (int)Fr, M, wpart, cpart, xs, pk, 3 * w.n_unit,
+                          G(prenet_conv1_b)))) return rc;
     hipLaunchKernelGGL(unpack_conv3_kernel, dim3(grid_for((int64_t)D * w.n_unit * 3)), dim3(256), 0, st, pk, D, w.n_unit,
                        G(prenet_conv1_w));
     DDSP_LAUNCH_CHECK(ctx);

@@ -68,7 +68,9 @@ class GradBucket:
     way per step otherwise).  autograd accumulates into an existing `.grad` in place, so the views survive a backward
     pass; `zero()` replaces `optimizer.zero_grad()` (whose default, set_to_none, would drop the views)."""
 
-    def __init__(self, params):
+    def __init__(self, params, model=None):
+        """`model`: the synthesiser whose parameters these are - its control network then receives its gradients directly
+        in the bucket (`Unit2Control._grads_in_place`) instead of through autograd's accumulation."""
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         ref = self.params[0]
@@ -77,6 +79,8 @@ class GradBucket:
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
+        if model is not None and hasattr(model, "unit2ctrl"):
+            model.unit2ctrl._grads_in_place = True
 
     def zero(self):
         self.flat.zero_()

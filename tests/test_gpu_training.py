@@ -272,7 +272,7 @@ def test_grad_bucket_train_step_equals_plain(dev, lib_path):
         model.train()
         opt = training.AdamW(model.parameters(), lr=5e-4, weight_decay=0.0)
         crit = RSSLoss(256, 2048, 4, device=dev)
-        bucket = training.GradBucket(model.parameters()) if use_bucket else None
+        bucket = training.GradBucket(model.parameters(), model) if use_bucket else None
         for step in range(2):
             loss = training.train_step(model, opt, crit, inp, scales=[300, 777, 1531, 2047], bucket=bucket)
         if use_bucket:
