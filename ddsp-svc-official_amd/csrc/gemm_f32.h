@@ -489,8 +489,9 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ?
             if (issue_tile < my_tiles) tile_src(tile_of(issue_tile), src_cur);
         }
     };
-    issue_next();
-    if (NS > 2) issue_next();
+    // NS - 1 steps in flight
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i) issue_next();
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -503,8 +504,10 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ?
     int kt = 0, tile_i = 0;
     for (int step = 0; step < steps; ++step) {
         // step has landed once at most the next step's pieces of THIS wave are still in flight ...
-        if (NS > 2 && step + 1 < steps)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        // (deeper rings: the last NS - 3 steps of the stream wait for everything, their successors being fewer than NS - 2)
+        static_assert((NS - 2) * PPW <= 63, "vmcnt is a 6-bit counter");
+        if (NS > 2 && step + NS - 2 < steps)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PPW) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // ... and every other wave says the same; the barrier also fences the reads of stage (step+2)%3 (step-1)
@@ -780,7 +783,14 @@ inline void launch(hipStream_t st, const Args& g, int batch, const Epi& epi) {
             small_dma = (e && e[0] == '0') ? 0 : 1;
         }
         if (small_dma && dma_ok(g) && blocks(64, 64) < 256 && g.K >= 256) {
-            dma_go<64, 64, Epi, 3, 4>(st, g, batch, epi);
+            static int small_ns = -1;
+            if (small_ns < 0) {
+                const char* e = getenv("DDSP_GEMM_SMALL_NS");
+                small_ns = e ? atoi(e) : 4;   // r02: real-time block replay 0.449 / 0.422 / 0.427 ms with 3 / 4 / 6 stages
+            }
+            if (small_ns == 6) dma_go<64, 64, Epi, 6, 4>(st, g, batch, epi);
+            else if (small_ns == 4) dma_go<64, 64, Epi, 4, 4>(st, g, batch, epi);
+            else dma_go<64, 64, Epi, 3, 4>(st, g, batch, epi);
             return;
         }
         if (dma_ok(g) && g.N <= 256 && blocks(64, 64) >= 256) {

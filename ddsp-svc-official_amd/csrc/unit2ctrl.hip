@@ -473,15 +473,31 @@ __global__ void __launch_bounds__(256) feature_map_kernel(float* __restrict__ fe
     }
 }
 
-// ks[b,h,j] = sum_n k'[b,n,h,j]   block = (b*8+h); thread j strides over features, loops frames
-__global__ void __launch_bounds__(320) key_sum_kernel(const float* __restrict__ kf, int Fr, float* __restrict__ ks) {
+// ks[b,h,j] = sum_n k'[b,n,h,j]   block = (b*8+h): 72 threads x 16 bytes cover the 288 padded features of a row, 8 frame
+// lanes walk the frames with two rows in flight each and meet in the LDS (one thread per feature walking all frames alone
+// read at 1.2 TB/s: 41 us per call at the training shape)
+constexpr int KS_T = LDF / 4;   // threads per row
+static_assert(LDF % 4 == 0 && KS_T * 8 <= 1024, "key_sum block");
+__global__ void __launch_bounds__(KS_T * 8) key_sum_kernel(const float* __restrict__ kf, int Fr, float* __restrict__ ks) {
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
-    const int j = threadIdx.x;
-    if (j >= LDF) return;
-    const float* base = kf + (((int64_t)b * Fr) * H + h) * LDF + j;
-    float s = 0.f;
-    for (int n = 0; n < Fr; ++n) s += base[(int64_t)n * H * LDF];
-    ks[(int64_t)bh * LDF + j] = s;
+    const int j4 = threadIdx.x % KS_T, fl = threadIdx.x / KS_T;
+    const float* base = kf + (((int64_t)b * Fr) * H + h) * LDF + 4 * j4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    int n = fl;
+    for (; n + 8 < Fr; n += 16) {
+        s0 += *(const f32x4*)(base + (int64_t)n * H * LDF);
+        s1 += *(const f32x4*)(base + (int64_t)(n + 8) * H * LDF);
+    }
+    if (n < Fr) s0 += *(const f32x4*)(base + (int64_t)n * H * LDF);
+    __shared__ f32x4 red[KS_T * 8];
+    red[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (fl == 0) {
+        f32x4 t = red[j4];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) t += red[i * KS_T + j4];
+        *(f32x4*)(ks + (int64_t)bh * LDF + 4 * j4) = t;
+    }
 }
 
 // dinv[r] = 1 / (q'[r,:] . ks[b,h,:] + 1e-8)   one wave per (frame, head) row
@@ -754,6 +770,79 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __rest
                                                   (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
 }
 
+// Up to four column sums that share their shape in ONE pass (blockIdx.z = job): the two LayerNorm / GroupNorm parameter
+// gradients (sums of gx and of dA), the three side-embedding weights and their bias (the same dX under four row weights).
+struct ColsumJobs {
+    const float* X[4];
+    const float* wsrc[4];
+    int wmode[4];
+    float* out[4];
+    int n;
+};
+__global__ void __launch_bounds__(256) colsum_multi_kernel(ColsumJobs jb, int64_t ld, int64_t rows, int cols,
+                                                           float* __restrict__ partial) {
+    const int job = blockIdx.z;
+    const float* __restrict__ X = jb.X[job];
+    const float* __restrict__ wsrc = jb.wsrc[job];
+    const int wmode = jb.wmode[job];
+    const int c = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int rl = threadIdx.x >> 6;
+    const int64_t per = (rows + CS_CHUNKS - 1) / CS_CHUNKS;
+    const int64_t r0 = (int64_t)blockIdx.y * per;
+    int64_t r1 = r0 + per;
+    if (r1 > rows) r1 = rows;
+    auto weight = [&](int64_t r) -> float {
+        if (wmode == 1) return wsrc[r];
+        if (wmode == 2) return logf(1.0f + __fdiv_rn(wsrc[r], 700.0f));
+        if (wmode == 3) return __fdiv_rn(wsrc[r], 3.14159274101257324f);
+        return 1.0f;
+    };
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    if (c < cols) {
+        int64_t r = r0 + rl;
+        for (; r + 4 < r1; r += 8) {
+            const f32x4 a = *(const f32x4*)(X + r * ld + c), b = *(const f32x4*)(X + (r + 4) * ld + c);
+            const float wa = weight(r), wb = weight(r + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s0[j] = fmaf(a[j], wa, s0[j]);
+                s1[j] = fmaf(b[j], wb, s1[j]);
+            }
+        }
+        if (r < r1) {
+            const f32x4 a = *(const f32x4*)(X + r * ld + c);
+            const float wa = weight(r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s0[j] = fmaf(a[j], wa, s0[j]);
+        }
+    }
+    __shared__ f32x4 red[256];
+    red[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (rl == 0 && c < cols)
+        *(f32x4*)(partial + ((int64_t)job * CS_CHUNKS + blockIdx.y) * cols + c) =
+            (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+}
+// the matching reduction: blockIdx.y = job, partial[job][chunk][cols] -> jb.out[job][cols]
+__global__ void __launch_bounds__(256) reduce_multi_kernel(const float* __restrict__ partial, ColsumJobs jb, int cols) {
+    const int job = blockIdx.y;
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), zl = threadIdx.x >> 6;
+    const float* p = partial + (int64_t)job * CS_CHUNKS * cols;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < cols) {
+#pragma unroll 4
+        for (int z = zl; z < CS_CHUNKS; z += 8) {
+            s0 += p[(int64_t)z * cols + i];
+            s1 += p[(int64_t)(z + 4) * cols + i];
+        }
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (zl == 0 && i < cols)
+        jb.out[job][i] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+}
+
 // out[i] = sum_{z < nz} partial[z][i]  (also the split-K reduction of the weight-gradient GEMMs)
 // block = 64 elements x 4 z-lanes (launch with 256 threads, ceil(n / 64) blocks): a thread adds every fourth partial in
 // two chains, the lanes meet in the LDS.  (One thread per element walked 128 partials alone: 10.5 us per call, 47 calls
@@ -846,16 +935,39 @@ __global__ void __launch_bounds__(256) attn_out_bwd_kernel(float* __restrict__ d
     if (lane == 0) dD[r] = -dot * di;
 }
 
-// d_ks[b,h,j] = sum_n q'[b,n,h,j] * d_D[b,n,h]
-__global__ void __launch_bounds__(320) weighted_key_sum_kernel(const float* __restrict__ qf, const float* __restrict__ dD,
-                                                               int Fr, float* __restrict__ dks) {
+// d_ks[b,h,j] = sum_n q'[b,n,h,j] * d_D[b,n,h]   (block layout of key_sum_kernel)
+__global__ void __launch_bounds__(KS_T * 8) weighted_key_sum_kernel(const float* __restrict__ qf, const float* __restrict__ dD,
+                                                                    int Fr, float* __restrict__ dks) {
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
-    const int j = threadIdx.x;
-    if (j >= LDF) return;
+    const int j4 = threadIdx.x % KS_T, fl = threadIdx.x / KS_T;
     const int64_t r0 = ((int64_t)b * Fr) * H + h;
-    float s = 0.f;
-    for (int n = 0; n < Fr; ++n) s = fmaf(qf[(r0 + (int64_t)n * H) * LDF + j], dD[r0 + (int64_t)n * H], s);
-    dks[(int64_t)bh * LDF + j] = s;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    int n = fl;
+    for (; n + 8 < Fr; n += 16) {
+        const f32x4 a = *(const f32x4*)(qf + (r0 + (int64_t)n * H) * LDF + 4 * j4);
+        const f32x4 c = *(const f32x4*)(qf + (r0 + (int64_t)(n + 8) * H) * LDF + 4 * j4);
+        const float wa = dD[r0 + (int64_t)n * H], wc = dD[r0 + (int64_t)(n + 8) * H];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s0[e] = fmaf(a[e], wa, s0[e]);
+            s1[e] = fmaf(c[e], wc, s1[e]);
+        }
+    }
+    if (n < Fr) {
+        const f32x4 a = *(const f32x4*)(qf + (r0 + (int64_t)n * H) * LDF + 4 * j4);
+        const float wa = dD[r0 + (int64_t)n * H];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s0[e] = fmaf(a[e], wa, s0[e]);
+    }
+    __shared__ f32x4 red[KS_T * 8];
+    red[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (fl == 0) {
+        f32x4 t = red[j4];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) t += red[i * KS_T + j4];
+        *(f32x4*)(dks + (int64_t)bh * LDF + 4 * j4) = t;
+    }
 }
 
 // feature-map adjoint, in place on d_feat: d_feat <- dn * d(dd);  coef[r] = -dn^2 * sum_j d_feat_j * E_j
@@ -1353,7 +1465,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
             PROF(PF_U2C_ROWWISE, 0, 4.0 * M8 * (2 * NF + DH),
                  hipLaunchKernelGGL(feature_map_kernel<false>, dim3(rows8_g), dim3(256), 0, st, b.kf, b.k, M8));
             PROF(PF_U2C_ROWWISE, 0, 4.0 * M8 * NF,
-                 hipLaunchKernelGGL(key_sum_kernel, dim3((unsigned)(B * H)), dim3(320), 0, st, b.kf, (int)Fr, b.ks));
+                 hipLaunchKernelGGL(key_sum_kernel, dim3((unsigned)(B * H)), dim3(KS_T * 8), 0, st, b.kf, (int)Fr, b.ks));
             {   // ctx[b,h] (266 x 64) = k'^T v : A stored [n][j] (K x M), B stored [n][e] (K x N)
                 gemm::Args g = gemm::make(b.kf, (int64_t)H * LDF, b.v, INNER, NF, DH, (int)Fr);
                 g.zdiv = H;
@@ -1519,6 +1631,31 @@ static int colsum(ddsp_ctx* ctx, hipStream_t st, const float* X, int64_t ld, int
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, partial, CS_CHUNKS, (int64_t)cols, out);
     DDSP_LAUNCH_CHECK(ctx);
     return DDSP_OK;
+}
+
+// several column sums of one shape in one pass (cols % 4 == 0, 16-byte aligned rows; cpart holds 4 x CS_CHUNKS x cols)
+static int colsum_multi(ddsp_ctx* ctx, hipStream_t st, const ColsumJobs& jb, int64_t ld, int64_t rows, int cols, float* partial) {
+    bool vec = cols % 4 == 0 && ld % 4 == 0 && ((uintptr_t)partial % 16) == 0 && (size_t)jb.n * cols <= 2048;
+    for (int i = 0; i < jb.n; ++i) vec = vec && ((uintptr_t)jb.X[i] % 16) == 0;
+    if (!vec) {
+        for (int i = 0; i < jb.n; ++i)
+            if (int rc = colsum(ctx, st, jb.X[i], ld, rows, cols, jb.wsrc[i], jb.wmode[i], partial, jb.out[i])) return rc;
+        return DDSP_OK;
+    }
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3((cols + 255) / 256, CS_CHUNKS, jb.n), dim3(256), 0, st, jb, ld, rows, cols, partial);
+    hipLaunchKernelGGL(reduce_multi_kernel, dim3((cols + 63) / 64, jb.n), dim3(256), 0, st, partial, jb, cols);
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}
+static int colsum_pair(ddsp_ctx* ctx, hipStream_t st, const float* X0, const float* X1, int64_t ld, int64_t rows, int cols,
+                       float* partial, float* out0, float* out1) {
+    ColsumJobs jb{};
+    jb.n = 2;
+    jb.X[0] = X0;
+    jb.X[1] = X1;
+    jb.out[0] = out0;
+    jb.out[1] = out1;
+    return colsum_multi(ctx, st, jb, ld, rows, cols, partial);
 }
 
 // Weight and bias gradient of one Linear (taps = 1) or Conv1d k=3 (taps = 3, X = the layer's input, out = the packed
@@ -1768,8 +1905,7 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
                        G(head_g), G(head_v));
     dgrad(st, d_ctrl, NO, bf.wh, NO, D, M, dA, false, wt_head);
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(rows_g), dim3(256), 0, st, bf.l[2].x_out, w.final_ln_w, dA, nullptr, M, dX, gx);
-    if ((rc = colsum(ctx, st, gx, D, M, D, nullptr, 0, cpart, G(final_ln_w)))) return rc;
-    if ((rc = colsum(ctx, st, dA, D, M, D, nullptr, 0, cpart, G(final_ln_b)))) return rc;
+    if ((rc = colsum_pair(ctx, st, gx, dA, D, M, D, cpart, G(final_ln_w), G(final_ln_b)))) return rc;
 
     for (int l = 2; l >= 0; --l) {
         const ddsp_u2c_layer& L = w.layer[l];
@@ -1792,8 +1928,7 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
                               GLP(cm_pw1_b)))) return rc;
         dgrad(st, dG1, 2 * INNER, L.cm_pw1_w, 2 * INNER, D, M, dA, false, wt_pw1[l]);                         // d_y2
         hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(rows_g), dim3(256), 0, st, b.x_mid, L.cm_ln_w, dA, dX, M, dX, gx);
-        if ((rc = colsum(ctx, st, gx, D, M, D, nullptr, 0, cpart, GLP(cm_ln_w)))) return rc;
-        if ((rc = colsum(ctx, st, dA, D, M, D, nullptr, 0, cpart, GLP(cm_ln_b)))) return rc;
+        if ((rc = colsum_pair(ctx, st, gx, dA, D, M, D, cpart, GLP(cm_ln_w), GLP(cm_ln_b)))) return rc;
         // dX now holds d x_mid
 
         // ===== attention: x_mid = x_in + to_out(attn) =====
@@ -1821,7 +1956,7 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
             gemm::EpiStore e{dcx, DH, nullptr, 1, (int64_t)NF * DH, 0};
             gemm::launch_tile<64, 64, false, false, gemm::A_PLAIN>(st, g, (int)(B * H), e);
         }
-        hipLaunchKernelGGL(weighted_key_sum_kernel, dim3((unsigned)(B * H)), dim3(320), 0, st, b.qf, dD, (int)Fr, dks);
+        hipLaunchKernelGGL(weighted_key_sum_kernel, dim3((unsigned)(B * H)), dim3(KS_T * 8), 0, st, b.qf, dD, (int)Fr, dks);
         {   // d_k' = v d_ctx^T + d_ks^T
             gemm::Args g = gemm::make(b.v, INNER, dcx, DH, (int)Fr, NF, DH);
             g.zdiv = H;
@@ -1862,17 +1997,26 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
             dgrad(st, dqkv[i], INNER, pw[i], INNER, D, M, dA, i > 0, wt_qkv[l][i]);                               // d_y (summed)
         }
         hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(rows_g), dim3(256), 0, st, b.x_in, L.norm_w, dA, dX, M, dX, gx);
-        if ((rc = colsum(ctx, st, gx, D, M, D, nullptr, 0, cpart, GLP(norm_w)))) return rc;
-        if ((rc = colsum(ctx, st, dA, D, M, D, nullptr, 0, cpart, GLP(norm_b)))) return rc;
+        if ((rc = colsum_pair(ctx, st, gx, dA, D, M, D, cpart, GLP(norm_w), GLP(norm_b)))) return rc;
         // dX now holds d x_in of this layer
 #undef GLP
     }
 
     // ---- side embeddings (x0 = conv2 + Lin(lf0) + Lin(phase/pi) + Lin(vol) + spk) ----
-    if ((rc = colsum(ctx, st, dX, D, M, D, in.f0, 2, cpart, G(f0_w)))) return rc;
-    if ((rc = colsum(ctx, st, dX, D, M, D, in.phase, 3, cpart, G(phase_w)))) return rc;
-    if ((rc = colsum(ctx, st, dX, D, M, D, in.volume, 1, cpart, G(volume_w)))) return rc;
-    if ((rc = colsum(ctx, st, dX, D, M, D, nullptr, 0, cpart, G(f0_b)))) return rc;
+    {
+        ColsumJobs jb{};
+        jb.n = 4;
+        const float* ws[4] = {in.f0, in.phase, in.volume, nullptr};
+        const int wm[4] = {2, 3, 1, 0};
+        float* outs[4] = {G(f0_w), G(phase_w), G(volume_w), G(f0_b)};
+        for (int i = 0; i < 4; ++i) {
+            jb.X[i] = dX;
+            jb.wsrc[i] = ws[i];
+            jb.wmode[i] = wm[i];
+            jb.out[i] = outs[i];
+        }
+        if ((rc = colsum_multi(ctx, st, jb, D, M, D, cpart))) return rc;
+    }
     DDSP_HIP(ctx, hipMemcpyAsync(G(phase_b), G(f0_b), D * sizeof(float), hipMemcpyDeviceToDevice, st));
     DDSP_HIP(ctx, hipMemcpyAsync(G(volume_b), G(f0_b), D * sizeof(float), hipMemcpyDeviceToDevice, st));
     DDSP_HIP(ctx, hipMemsetAsync(G(spk_table), 0, (size_t)w.n_spk * D * sizeof(float), st));
@@ -1895,8 +2039,7 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
                        w.prenet_gn_w, (int)Fr, gbst);
     hipLaunchKernelGGL(groupnorm_bwd_apply_kernel, dim3(grid_for(M * D)), dim3(256), 0, st, bf.t1, bf.t2, dA, bf.gst, gbst,
                        w.prenet_gn_w, M, (int)Fr, dX, gx, dA);                                     // dX = d_t1, dA = d_gn
-    if ((rc = colsum(ctx, st, gx, D, M, D, nullptr, 0, cpart, G(prenet_gn_w)))) return rc;
-    if ((rc = colsum(ctx, st, dA, D, M, D, nullptr, 0, cpart, G(prenet_gn_b)))) return rc;
+    if ((rc = colsum_pair(ctx, st, gx, dA, D, M, D, cpart, G(prenet_gn_w), G(prenet_gn_b)))) return rc;
     // ---- prenet conv1 (the units carry no gradient) ----
     if ((rc = layer_grads(ctx, st, dX, D, D, in.units, w.n_unit, w.n_unit, 3, (int)Fr, M, wpart, cpart, xs, pk, 3 * w.n_unit,
                           G(prenet_conv1_b)))) return rc;
