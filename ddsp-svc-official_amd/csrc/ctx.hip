@@ -3,7 +3,7 @@
 
 #include <stdlib.h>
 
-#define DDSP_ABI_VERSION 1
+#define DDSP_ABI_VERSION 2   // 2: ddsp_rss_loss takes the hops
 
 extern "C" int ddsp_abi_version(void) { return DDSP_ABI_VERSION; }
 

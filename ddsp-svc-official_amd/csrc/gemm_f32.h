@@ -744,6 +744,8 @@ inline void dma_go(hipStream_t st, const Args& g0, int batch, const Epi& epi, in
         launch_dma<BM, BN, Epi, NS, 0, NW, A_MODE, 7>(st, h, batch, epi, total_override);
     } else if (g.math == 3)
         launch_dma<BM, BN, Epi, NS, 0, NW, A_MODE, 3>(st, g, batch, epi, total_override);
+    else if (g.math == 6)   // three bf16 pieces per operand, six products: fp32-class error (2.4e-7), callers that ask for it
+        launch_dma<BM, BN, Epi, NS, 0, NW, A_MODE, 6>(st, g, batch, epi, total_override);
     else
         launch_dma<BM, BN, Epi, NS, 0, NW, A_MODE, 0>(st, g, batch, epi, total_override);
 }

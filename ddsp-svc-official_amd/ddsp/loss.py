@@ -4,8 +4,8 @@ gradient w.r.t. the prediction come from hand-written kernels; no CPU fallback).
 `RSSLoss(fft_min, fft_max, n_scale, alpha=1.0, overlap=0, eps=1e-7, device='cuda')(x_pred, x_true)` draws
 `n_scale` integers in [fft_min, fft_max) with `torch.randint` per call exactly like the reference
 (`ddsp/loss.py:39`), so seeding torch reproduces the reference's sequence of scales; `set_scales` pins the next
-draw (tests, and data-parallel ranks that must share one draw - SURVEY 8e).  Only `overlap=0` (the only value the
-reference's callers use, `train.py:48`) is built.
+draw (tests, and data-parallel ranks that must share one draw - SURVEY 8e).  `overlap` sets the hop as the reference
+does, `int(n_fft * (1 - overlap))` (`ddsp/loss.py:13`); its callers use 0 (`train.py:48`).
 """
 import torch
 import torch.nn as nn
@@ -15,10 +15,11 @@ import hipddsp
 
 class _SpectralLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_pred, x_true, n_ffts, alpha, eps):
+    def forward(ctx, x_pred, x_true, n_ffts, alpha, eps, overlap=0):
         c = hipddsp.context_for(x_pred.device)
         need = x_pred.requires_grad
-        loss, grad = c.rss_loss(x_pred, x_true, n_ffts, alpha, eps, want_grad=need)
+        hops = None if overlap == 0 else [_hop(n, overlap) for n in n_ffts]
+        loss, grad = c.rss_loss(x_pred, x_true, n_ffts, alpha, eps, want_grad=need, hops=hops)
         ctx.grad = grad
         return loss.reshape(())
 
@@ -26,12 +27,17 @@ class _SpectralLossFn(torch.autograd.Function):
     def backward(ctx, g):
         grad = ctx.grad
         ctx.grad = None
-        return (grad * g if grad is not None else None), None, None, None, None
+        return (grad * g if grad is not None else None), None, None, None, None, None
+
+
+def _hop(n_fft, overlap):
+    """The reference's hop (`ddsp/loss.py:13`), in Python floats like there."""
+    return int(n_fft * (1 - overlap))
 
 
 def _check(x_pred, x_true, overlap):
-    if overlap != 0:
-        raise ValueError("only overlap=0 (hop == n_fft) is built, as in every reference caller")
+    if not 0 <= overlap < 1:
+        raise ValueError("overlap must lie in [0, 1)")
     if not x_pred.is_cuda:
         raise RuntimeError("the spectral loss runs on a HIP device only (no CPU fallback)")
 
@@ -45,7 +51,7 @@ class SSSLoss(nn.Module):
 
     def forward(self, x_true, x_pred):
         _check(x_pred, x_true, self.overlap)
-        return _SpectralLossFn.apply(x_pred, x_true.to(x_pred.dtype), [self.n_fft], self.alpha, self.eps)
+        return _SpectralLossFn.apply(x_pred, x_true.to(x_pred.dtype), [self.n_fft], self.alpha, self.eps, self.overlap)
 
 
 class RSSLoss(nn.Module):
@@ -70,4 +76,4 @@ class RSSLoss(nn.Module):
             n_ffts = [int(v) for v in torch.randint(self.fft_min, self.fft_max, (self.n_scale,))]
         self.last_scales = n_ffts
         # cached training audio may be fp16 (reference data_loaders.py:81-83): promote the target
-        return _SpectralLossFn.apply(x_pred, x_true.to(torch.float32), n_ffts, self.alpha, self.eps)
+        return _SpectralLossFn.apply(x_pred, x_true.to(torch.float32), n_ffts, self.alpha, self.eps, self.overlap)

@@ -68,7 +68,7 @@ SIGNATURES = {
     "ddsp_spectral_ola": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _int, _u64, _i64, _i64, _int, _vp]),
     "ddsp_sins_bank_bwd": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _i64, _i64, _int, _int, _vp, _i64]),
     "ddsp_spectral_ola_bwd": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _int, _u64, _vp, _i64, _i64, _int, _vp, _i64]),
-    "ddsp_rss_loss": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _c.POINTER(_int), _int, _f32, _f32, _vp, _vp]),
+    "ddsp_rss_loss": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _c.POINTER(_int), _c.POINTER(_int), _int, _f32, _f32, _vp, _vp]),
     "ddsp_sola": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _vp]),
     "ddsp_volume_gate": (_int, [_vp, _vp, _vp, _vp, _f32, _i64, _i64, _int]),
     "ddsp_phase_vocoder": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
@@ -480,8 +480,9 @@ class Context:
         return d_ctrl
 
     # -- a13 -----------------------------------------------------------------------------------
-    def rss_loss(self, x_pred, x_true, n_ffts, alpha=1.0, eps=1e-7, want_grad=False):
-        """-> (loss (1,) device tensor, d loss/d x_pred (B,T) | None) for the given list of scales."""
+    def rss_loss(self, x_pred, x_true, n_ffts, alpha=1.0, eps=1e-7, want_grad=False, hops=None):
+        """-> (loss (1,) device tensor, d loss/d x_pred (B,T) | None) for the given list of scales; `hops`: one hop per
+        scale (default: hop = n_fft, the reference's overlap = 0)."""
         xp = x_pred.detach().contiguous().float()
         xt = x_true.detach().contiguous().float()
         B, T = xp.shape
@@ -490,9 +491,12 @@ class Context:
         if T % 4:
             raise ValueError("signal length must be a multiple of 4")
         arr = (_int * len(n_ffts))(*[int(n) for n in n_ffts])
+        if hops is not None and len(hops) != len(n_ffts):
+            raise ValueError("one hop per scale")
+        harr = (_int * len(n_ffts))(*[int(h) for h in hops]) if hops is not None else None
         loss = torch.empty(1, device=xp.device, dtype=torch.float32)
         grad = torch.empty_like(xp) if want_grad else None
-        self.call("ddsp_rss_loss", _ptr(xp), _ptr(xt), B, T, arr, len(n_ffts), float(alpha), float(eps), _ptr(loss),
+        self.call("ddsp_rss_loss", _ptr(xp), _ptr(xt), B, T, arr, harr, len(n_ffts), float(alpha), float(eps), _ptr(loss),
                   _ptr(grad))
         return loss, grad
 

@@ -198,12 +198,15 @@ int ddsp_spectral_ola_bwd(ddsp_ctx* ctx, void* stream, const float* ctrl, int64_
 /* ---- a13: random-scale spectral loss ---------------------------------------------------------- */
 /* replaces ddsp/loss.py:7-43 `RSSLoss.forward(x_pred, x_true)` for a given draw of scales: n_ffts_host holds the
  * n_scale values the reference draws with torch.randint(fft_min, fft_max) (ddsp/loss.py:39; the caller draws, so
- * data-parallel ranks can share one draw).  Per scale N: Hann(periodic) window, hop = N, center=False, magnitude
- * / sqrt(sum w^2) + eps; L_N = mean_b ||S_t-S_p||_F/||S_t+S_p||_F + alpha*mean|ln S_t - ln S_p|; loss = mean_N.
+ * data-parallel ranks can share one draw).  Per scale N: Hann(periodic) window, center=False, hop = hops_host[s] -
+ * the caller evaluates the reference's `int(n_fft * (1 - overlap))` (ddsp/loss.py:13) in its own floating point - or
+ * hop = N when hops_host is NULL (overlap = 0, what every reference caller uses); magnitude / sqrt(sum w^2) + eps;
+ * L_N = mean_b ||S_t-S_p||_F/||S_t+S_p||_F + alpha*mean|ln S_t - ln S_p|; loss = mean_N.
  * x_pred, x_true (B,T) 16-byte aligned, T % 4 == 0; loss: device float[1]; grad_pred (B,T) or NULL receives
  * d loss / d x_pred (the caller's autograd scales it by the upstream gradient). */
 int ddsp_rss_loss(ddsp_ctx* ctx, void* stream, const float* x_pred, const float* x_true, int64_t B, int64_t T,
-                  const int* n_ffts_host, int n_scale, float alpha, float eps, float* loss, float* grad_pred);
+                  const int* n_ffts_host, const int* hops_host, int n_scale, float alpha, float eps, float* loss,
+                  float* grad_pred);
 
 /* ---- a14: SOLA splice of the real-time path -------------------------------------------------- */
 /* replaces gui.py:405-430: within audio[-block-xfade-search-delay : -delay] find the lag (0..search) that

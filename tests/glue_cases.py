@@ -19,6 +19,9 @@ def f32(a):
 LOSS_SCALES = [256, 257, 1000, 1531, 2047]          # smallest, a prime, an even mid size, an odd composite, the largest
 LOSS_BT = (3, 88064)
 RSS_SEED = 11                                       # torch.manual_seed before RSSLoss.forward (its randint draw)
+# (n_fft, overlap) of tests/golden/ref_loss_overlap.npz: hops 250, 128, 1432 (a frame count of 1 + (T - N)//hop each),
+# and one whose hop int(N * (1 - overlap)) is decided by the floating-point product (1531 * 0.3 = 459.3 -> 459)
+LOSS_OVERLAP_CASES = [(1000, 0.75), (257, 0.5), (2047, 0.3), (1531, 0.7)]
 
 
 def loss_signals(seed=1, B=LOSS_BT[0], T=LOSS_BT[1]):

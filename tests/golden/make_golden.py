@@ -699,8 +699,46 @@ def tier_g():
         del sys.modules[k]
 
 
+def tier_h():
+    """ref_loss_overlap.npz: `ddsp/loss.py` SSSLoss with overlap > 0 (hop = int(n_fft * (1 - overlap)), ddsp/loss.py:13) and
+    one RSSLoss(overlap=0.75) call, executed like G8 (Spectrogram placeholder on torch.stft: that boundary is unpinned)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import glue_cases as GC
+    _placeholders()
+    _spectrogram_placeholder()
+    _fresh_reference()
+    import ddsp.loss as RL
+    assert RL.__file__.startswith(REF)
+    xp, xt = GC.loss_signals()
+    g = {}
+    for N, ov in GC.LOSS_OVERLAP_CASES:
+        x = xp.clone().requires_grad_(True)
+        v = RL.SSSLoss(N, overlap=ov)(xt, x)
+        v.backward()
+        g[f"sss_{N}"] = v.detach()
+        g[f"sss_grad_{N}"] = x.grad[:, ::97]
+        x64 = xp.double().clone().requires_grad_(True)
+        v64 = RL.SSSLoss(N, overlap=ov).double()(xt.double(), x64)
+        v64.backward()
+        g[f"sss64_{N}"] = v64.detach()
+        g[f"sss64_grad_{N}"] = x64.grad[:, ::97]
+        g[f"sss64_gradnorm_{N}"] = x64.grad.norm()
+        g[f"hop_{N}"] = torch.tensor(RL.SSSLoss(N, overlap=ov).spec.hop)
+    crit = RL.RSSLoss(256, 300, 2, overlap=0.75, device="cpu")       # a narrow range keeps the 44 module constructions cheap
+    torch.manual_seed(GC.RSS_SEED)
+    x = xp.clone().requires_grad_(True)
+    v = crit(x, xt)
+    v.backward()
+    torch.manual_seed(GC.RSS_SEED)
+    g["rss_scales"] = torch.randint(256, 300, (2,))
+    g["rss"] = v.detach()
+    g["rss_grad"] = x.grad[:, ::97]
+    g["rss_gradnorm"] = x.grad.norm()
+    save("ref_loss_overlap.npz", **g)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["a", "b", "c", "d", "e", "f", "g"]
+    which = sys.argv[1:] or ["a", "b", "c", "d", "e", "f", "g", "h"]
     torch.set_num_threads(4)
     if "a" in which:
         tier_a()
@@ -716,3 +754,5 @@ if __name__ == "__main__":
         tier_f()
     if "g" in which:
         tier_g()
+    if "h" in which:
+        tier_h()

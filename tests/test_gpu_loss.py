@@ -74,7 +74,7 @@ def test_rss_module_api(dev, lib_path):
     s = SSSLoss(300)(xt.to(dev), xp.detach())
     assert abs(float(s) - float(OL.sss_loss(xt, xp.detach().cpu(), 300))) < 2e-5
     with pytest.raises(ValueError):
-        RSSLoss(256, 2048, 4, overlap=0.5)(xp, xt.to(dev))
+        RSSLoss(256, 2048, 4, overlap=1.0)(xp, xt.to(dev))
 
 
 def test_rss_against_reference_run(ctx, dev):
@@ -108,3 +108,43 @@ def test_rss_against_reference_run(ctx, dev):
     gw = torch.from_numpy(z["rss_grad"])
     assert float((x.grad.cpu()[:, ::97] - gw).norm() / gw.norm()) < 5e-3
     assert abs(float(x.grad.norm()) - float(z["rss_gradnorm"])) < 5e-3 * float(z["rss_gradnorm"])
+
+
+def test_overlap_against_reference_run(ctx, dev):
+    """overlap > 0: hop = int(n_fft * (1 - overlap)) (ddsp/loss.py:13), frames gathered with that hop, their gradients
+    overlap-added.  Against the reference's own run (tests/golden/ref_loss_overlap.npz, make_golden.py tier h) and, for the
+    full gradient, the oracle in fp64."""
+    import os
+    import glue_cases as GC
+    from conftest import GOLDEN
+    from ddsp.loss import RSSLoss, SSSLoss
+    z = np.load(os.path.join(GOLDEN, "ref_loss_overlap.npz"))
+    xp, xt = GC.loss_signals()
+    for N, ov in GC.LOSS_OVERLAP_CASES:
+        x = xp.to(dev).requires_grad_(True)
+        v = SSSLoss(N, overlap=ov)(xt.to(dev), x)
+        v.backward()
+        assert abs(float(v.detach()) - float(z[f"sss_{N}"])) < 2e-5 * float(z[f"sss_{N}"]), N
+        g64 = torch.from_numpy(z[f"sss64_grad_{N}"])
+        ref_err = float((torch.from_numpy(z[f"sss_grad_{N}"]).double() - g64).norm() / g64.norm())
+        err = float((x.grad.cpu()[:, ::97].double() - g64).norm() / g64.norm())
+        assert err < max(3 * ref_err, 4e-3), (N, err, ref_err)
+        assert abs(float(x.grad.norm()) - float(z[f"sss64_gradnorm_{N}"])) < max(3 * ref_err, 4e-3) * float(z[f"sss64_gradnorm_{N}"])
+    crit = RSSLoss(256, 300, 2, overlap=0.75, device=dev)
+    x = xp.to(dev).requires_grad_(True)
+    torch.manual_seed(GC.RSS_SEED)
+    v = crit(x, xt.to(dev))
+    v.backward()
+    assert crit.last_scales == [int(s) for s in z["rss_scales"]]
+    assert abs(float(v.detach()) - float(z["rss"])) < 2e-5 * float(z["rss"])
+    gw = torch.from_numpy(z["rss_grad"])
+    assert float((x.grad.cpu()[:, ::97] - gw).norm() / gw.norm()) < 5e-3
+    # the whole gradient (every sample, including the stretch after the last frame) against the oracle in fp64
+    x64 = xp.double().clone().requires_grad_(True)
+    OL.rss_loss(x64, xt.double(), [777, 300], overlap=0.6).backward()
+    _, grad = ctx.rss_loss(xp.to(dev), xt.to(dev), [777, 300], want_grad=True, hops=[int(777 * (1 - 0.6)), int(300 * (1 - 0.6))])
+    assert float((grad.cpu().double() - x64.grad).norm() / x64.grad.norm()) < 4e-3
+    tail = 88064 - ((88064 - 300) // 120 * 120 + 300)
+    assert tail > 0 and torch.equal(grad[:, -tail:].cpu(), x64.grad[:, -tail:].float())   # exact zeros
+    with pytest.raises(ValueError):
+        ctx.rss_loss(xp.to(dev), xt.to(dev), [300], hops=[301])

@@ -240,6 +240,30 @@ def test_loss_oracle_against_reference_run():
     assert abs(float(x.grad.norm()) - g["rss_gradnorm"]) < 2e-3 * g["rss_gradnorm"]
 
 
+def test_loss_overlap_oracle_against_reference_run():
+    """overlap > 0 (hop = int(n_fft * (1 - overlap)), ddsp/loss.py:13): oracle/loss.py against the reference's SSSLoss /
+    RSSLoss run with overlap (tests/golden/ref_loss_overlap.npz, make_golden.py tier h)."""
+    import glue_cases as GC
+    from oracle import loss as OL
+    g = load("ref_loss_overlap.npz")
+    xp, xt = GC.loss_signals()
+    for N, ov in GC.LOSS_OVERLAP_CASES:
+        assert OL.hop_length(N, ov) == int(g[f"hop_{N}"])
+        x = xp.clone().requires_grad_(True)
+        v = OL.sss_loss(xt, x, N, overlap=ov)
+        v.backward()
+        assert abs(float(v.detach()) - g[f"sss_{N}"]) < 2e-6 * g[f"sss_{N}"], N
+        ref_err = float((g[f"sss_grad_{N}"].double() - g[f"sss64_grad_{N}"]).norm() / g[f"sss64_grad_{N}"].norm())
+        err = float((x.grad[:, ::97].double() - g[f"sss64_grad_{N}"]).norm() / g[f"sss64_grad_{N}"].norm())
+        assert err < max(3 * ref_err, 1e-5), (N, err, ref_err)
+    scales = [int(v) for v in g["rss_scales"]]
+    x = xp.clone().requires_grad_(True)
+    v = OL.rss_loss(x, xt, scales, overlap=0.75)
+    v.backward()
+    assert abs(float(v.detach()) - g["rss"]) < 2e-6 * g["rss"]
+    assert float((x.grad[:, ::97] - g["rss_grad"]).norm() / g["rss_grad"].norm()) < 2e-3
+
+
 def oracle_train_steps(steps=None):
     """Three iterations of solver.py:110-114 through the oracle forward, the oracle loss, PyTorch autograd and
     torch.optim.AdamW; shared by the CPU pin below and the GPU test."""
