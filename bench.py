@@ -56,11 +56,14 @@ KERNEL_LABEL = {
 }
 
 
-def measured_traffic(family):
+def measured_traffic(family, split=True):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in
     separate runs, FETCH doubled per MI355X_MICROARCH 'HBM'; tools/pmc_traffic.py).  PMC collection needs the profiler
-    around the process, so bench.py reads the last committed measurement instead of taking it live; None when absent."""
+    around the process, so bench.py reads the last committed measurement instead of taking it live; None when absent.
+    The profiled command runs both legs; `split` picks the GEMM instantiations of one of them (last template argument of
+    gemm::kernel_dma: 3 / 7 / 8 = split-bf16 products, 0 = fp32 products)."""
     import glob
+    import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_per_launch.json")))
     if not files:
         return None
@@ -68,7 +71,7 @@ def measured_traffic(family):
     tot = n = 0.0
     for k, v in d.items():
         if family == "ltv_fir":
-            if k.startswith("ltv_fir_kernel") or "ltv_fir_bf16" in k:
+            if ("ltv_fir_bf16" in k) if split else k.startswith("ltv_fir_kernel"):
                 tot += v["hbm_bytes_per_launch"] * v["launches_sampled"]
                 n += v["launches_sampled"]
         # the Linear layers' instantiations at the bench shape (QKV, pw1+GLU, out-projection / pw2, head); the same
@@ -77,6 +80,9 @@ def measured_traffic(family):
             return None          # no PMC pass committed for this family
         elif "kernel_dma" in k and any(t in k for t in ("EpiSplit3", "EpiGlu", "EpiResidual",
                                                         "kernel_dma<128, 128, gemm::EpiStore")):
+            m = re.search(r", (\d+)>\(", k)
+            if m and (int(m.group(1)) in (3, 7, 8)) != bool(split):
+                continue
             tot += v["hbm_bytes_per_launch"] * v["launches_sampled"]
             # per GEMM CALL: the QKV call is two kernels (its 128x128 tiles and the 64x64 remainder of the last round)
             if "kernel_dma<64, 64, EpiSplit3" not in k:
@@ -318,7 +324,7 @@ def main():
             avg_ms = d["ms_total"] / d["launches"]
             alg = d["flops_total"] / d["launches"] / (avg_ms * 1e-3) / 1e12
             r = {"kernel": KERNEL_LABEL[name], "bound": "mfma", "unit": "TFLOP/s",
-                 "traffic": measured_traffic(name) if split else None, "avg_launch_ms": avg_ms, "launches": d["launches"],
+                 "traffic": measured_traffic(name, split), "avg_launch_ms": avg_ms, "launches": d["launches"],
                  "ms_per_step": d["ms_total"] / args.steps,
                  "algorithmic_bytes_per_launch": d["bytes_total"] / d["launches"],
                  "algorithmic_flops_per_launch": d["flops_total"] / d["launches"]}
