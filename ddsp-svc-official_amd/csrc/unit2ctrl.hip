@@ -1186,7 +1186,8 @@ __global__ void __launch_bounds__(256) weight_norm_bwd_kernel(const float* __res
 // speaker's row (atomics: several utterances may share a speaker), or w_k * (sum over everything) in mix mode
 __global__ void __launch_bounds__(256) spk_embed_bwd_kernel(const float* __restrict__ dx, int64_t B, int Fr,
                                                             const int64_t* __restrict__ spk_id, int64_t n_spk_id,
-                                                            MixArgs mix, float* __restrict__ dtable, int n_spk) {
+                                                            MixArgs mix, float* __restrict__ dtable, int n_spk,
+                                                            int* __restrict__ err) {
     const int c = threadIdx.x;  // D == 256 channels
     const int64_t b = blockIdx.x;
     float s = 0.f;
@@ -1195,7 +1196,10 @@ __global__ void __launch_bounds__(256) spk_embed_bwd_kernel(const float* __restr
         for (int k = 0; k < mix.n; ++k) atomicAdd(dtable + (mix.ids[k] - 1) * D + c, mix.w[k] * s);
     } else {
         const int64_t id = spk_id[n_spk_id == 1 ? 0 : b];
-        if (id >= 1 && id <= n_spk) atomicAdd(dtable + (id - 1) * D + c, s);   // (the forward has raised the error flag)
+        if (id >= 1 && id <= n_spk)
+            atomicAdd(dtable + (id - 1) * D + c, s);
+        else if (c == 0)   // skipped, and reported by the next call / ddsp_ctx_poll_error (like the forward's table read)
+            __hip_atomic_store(err, DDSP_DEV_ERR_SPK_ID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1229,11 +1233,22 @@ struct Arena {  // sizes first (dry run), then pointers
     bool dry;
     size_t total;
     int rc;
+    char* ext = nullptr;   // a caller-owned region instead of the context's scratch (kept activations of a training step)
+    size_t ext_cap = 0;
     float* get(size_t n_floats) {
         const size_t bytes = ((n_floats * sizeof(float) + 255) & ~(size_t)255) + 256;
         if (dry) {
             total += bytes;
             return nullptr;
+        }
+        if (ext) {
+            if (total + bytes > ext_cap) {
+                rc = DDSP_ERR_ARG;
+                return nullptr;
+            }
+            float* p = reinterpret_cast<float*>(ext + total);
+            total += bytes;
+            return p;
         }
         void* p = nullptr;
         const int r = ddsp_scratch_get(ctx, n_floats * sizeof(float), &p);
@@ -1804,34 +1819,24 @@ extern "C" int ddsp_unit2ctrl_fwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
     return u2c_forward(ctx, st, w, in, bf, ctrl);
 }
 
-extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_weights* wp, const float* units,
-                                  const float* f0_frames, const float* phase_frames, const float* volume,
-                                  const int64_t* spk_id, int64_t n_spk_id, const int64_t* mix_ids_host,
-                                  const float* mix_w_host, int n_mix, int64_t B, int64_t Fr, const float* d_ctrl,
-                                  const ddsp_u2c_weights* grads_host, float* ctrl_out) {
-    U2CInputs in;
-    int rc = check_inputs(ctx, wp, units, f0_frames, phase_frames, volume, spk_id, n_spk_id, mix_ids_host, mix_w_host,
-                          n_mix, B, Fr, in);
-    if (rc) return rc;
-    DDSP_REQUIRE(ctx, d_ctrl && grads_host, "ddsp_unit2ctrl_bwd: null argument");
-    DDSP_REQUIRE(ctx, !wp->causal, "ddsp_unit2ctrl_bwd: the causal network (c: true) is built for inference only");
-    if ((rc = ddsp_take_dev_error(ctx))) return rc;
-    if (B == 0) return DDSP_OK;
-    hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
-    const ddsp_u2c_weights w = *wp;
-    const ddsp_u2c_weights gr = *grads_host;  // same layout; the pointers are written through
+// the backward pass; `keep` = the activation region a ddsp_unit2ctrl_fwd_keep call filled (then nothing is recomputed), or
+// null: the forward is re-run here with its activations in the scratch arena
+static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w, const ddsp_u2c_weights& gr, const U2CInputs& in,
+                        int64_t B, int64_t Fr, const float* d_ctrl, float* ctrl_out, void* keep, size_t keep_bytes) {
+    int rc;
 #define G(p) const_cast<float*>(gr.p)
     const int64_t M = B * Fr, M8 = M * H;
     const int NO = w.n_out;
 
     // ---- arena: kept forward activations + backward temporaries ----
     U2CBufs bf;
-    float *ctrl, *dX, *dA, *dB512, *dC512, *dV512, *dG1, *dQF, *dKF, *dcx, *dks, *dD, *coefq, *coefk, *gx, *wpart, *cpart,
+    float *ctrl = nullptr, *dX, *dA, *dB512, *dC512, *dV512, *dG1, *dQF, *dKF, *dcx, *dks, *dD, *coefq, *coefk, *gx, *wpart, *cpart,
         *dWh, *pk, *xs, *dwpart, *gbst, *w2t, *wts;
     auto plan_bwd = [&](Arena& a) {
-        plan_forward(a, bf, w, B, Fr, true);
-        ctrl = a.get((size_t)M * NO);
+        if (!keep) {
+            plan_forward(a, bf, w, B, Fr, true);
+            ctrl = a.get((size_t)M * NO);
+        }
         dX = a.get((size_t)M * D);          // gradient on the residual stream
         dA = a.get((size_t)M * D);          // second stream-sized temporary
         dB512 = a.get((size_t)M * INNER);   // d_dwo / d_pre / d_attn->d_num / d_q
@@ -1857,6 +1862,11 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
         w2t = a.get((size_t)D * 3 * D);
         wts = a.get((size_t)NO * D + 3 * ((size_t)2 * D * INNER + (size_t)2 * INNER * D + (size_t)3 * INNER * D));
     };
+    if (keep) {
+        Arena k{ctx, false, 0, 0, (char*)keep, keep_bytes};
+        plan_forward(k, bf, w, B, Fr, true);
+        DDSP_REQUIRE(ctx, !k.rc, "ddsp_unit2ctrl_bwd_kept: the activation region is smaller than ddsp_unit2ctrl_keep_bytes says");
+    }
     Arena dry{ctx, true, 0, 0};
     plan_bwd(dry);
     rc = ddsp_scratch_reserve_bytes(ctx, dry.total + 4096);
@@ -1866,9 +1876,11 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
     plan_bwd(a);
     if (a.rc) return a.rc;
 
-    rc = u2c_forward(ctx, st, w, in, bf, ctrl);
-    if (rc) return rc;
-    if (ctrl_out) DDSP_HIP(ctx, hipMemcpyAsync(ctrl_out, ctrl, (size_t)M * NO * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (!keep) {
+        rc = u2c_forward(ctx, st, w, in, bf, ctrl);
+        if (rc) return rc;
+        if (ctrl_out) DDSP_HIP(ctx, hipMemcpyAsync(ctrl_out, ctrl, (size_t)M * NO * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
 
     const unsigned rows_g = (unsigned)ceil_div64(M, 4), rows8_g = (unsigned)ceil_div64(M8, 4);
     // ---- transposed split copies of the weights for the input-gradient products (split-bf16 arithmetic only) ----
@@ -2020,8 +2032,10 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
     DDSP_HIP(ctx, hipMemcpyAsync(G(phase_b), G(f0_b), D * sizeof(float), hipMemcpyDeviceToDevice, st));
     DDSP_HIP(ctx, hipMemcpyAsync(G(volume_b), G(f0_b), D * sizeof(float), hipMemcpyDeviceToDevice, st));
     DDSP_HIP(ctx, hipMemsetAsync(G(spk_table), 0, (size_t)w.n_spk * D * sizeof(float), st));
+    int* dev_err = nullptr;
+    if ((rc = ddsp_dev_error_ptr(ctx, &dev_err))) return rc;
     hipLaunchKernelGGL(spk_embed_bwd_kernel, dim3((unsigned)B), dim3(D), 0, st, dX, B, (int)Fr, in.spk_id, in.n_spk_id,
-                       in.mix, G(spk_table), w.n_spk);
+                       in.mix, G(spk_table), w.n_spk, dev_err);
     // ---- prenet conv2: weight gradient over the three taps, input gradient as the flipped conv ----
     if ((rc = layer_grads(ctx, st, dX, D, D, bf.t2, D, D, 3, (int)Fr, M, wpart, cpart, xs, pk, 3 * D, G(prenet_conv2_b)))) return rc;
     hipLaunchKernelGGL(unpack_conv3_kernel, dim3(grid_for((int64_t)D * D * 3)), dim3(256), 0, st, pk, D, D, G(prenet_conv2_w));
@@ -2048,4 +2062,68 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
     DDSP_LAUNCH_CHECK(ctx);
 #undef G
     return DDSP_OK;
+}
+
+extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_weights* wp, const float* units,
+                                  const float* f0_frames, const float* phase_frames, const float* volume,
+                                  const int64_t* spk_id, int64_t n_spk_id, const int64_t* mix_ids_host,
+                                  const float* mix_w_host, int n_mix, int64_t B, int64_t Fr, const float* d_ctrl,
+                                  const ddsp_u2c_weights* grads_host, float* ctrl_out) {
+    U2CInputs in;
+    int rc = check_inputs(ctx, wp, units, f0_frames, phase_frames, volume, spk_id, n_spk_id, mix_ids_host, mix_w_host,
+                          n_mix, B, Fr, in);
+    if (rc) return rc;
+    DDSP_REQUIRE(ctx, d_ctrl && grads_host, "ddsp_unit2ctrl_bwd: null argument");
+    DDSP_REQUIRE(ctx, !wp->causal, "ddsp_unit2ctrl_bwd: the causal network (c: true) is built for inference only");
+    if ((rc = ddsp_take_dev_error(ctx))) return rc;
+    if (B == 0) return DDSP_OK;
+    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    return u2c_backward(ctx, (hipStream_t)stream, *wp, *grads_host, in, B, Fr, d_ctrl, ctrl_out, nullptr, 0);
+}
+
+// ---- a training step's pair: a forward that leaves its activations in a caller-owned region, a backward that starts from them ----
+extern "C" int64_t ddsp_unit2ctrl_keep_bytes(const ddsp_u2c_weights* wp, int64_t B, int64_t Fr) {
+    if (!wp || B < 0 || Fr < 1) return -1;
+    U2CBufs bf;
+    Arena dry{nullptr, true, 0, 0};
+    plan_forward(dry, bf, *wp, B, Fr, true);
+    return (int64_t)dry.total + 256;
+}
+
+extern "C" int ddsp_unit2ctrl_fwd_keep(ddsp_ctx* ctx, void* stream, const ddsp_u2c_weights* wp, const float* units,
+                                       const float* f0_frames, const float* phase_frames, const float* volume,
+                                       const int64_t* spk_id, int64_t n_spk_id, const int64_t* mix_ids_host,
+                                       const float* mix_w_host, int n_mix, int64_t B, int64_t Fr, void* keep,
+                                       int64_t keep_bytes, float* ctrl) {
+    U2CInputs in;
+    int rc = check_inputs(ctx, wp, units, f0_frames, phase_frames, volume, spk_id, n_spk_id, mix_ids_host, mix_w_host,
+                          n_mix, B, Fr, in);
+    if (rc) return rc;
+    DDSP_REQUIRE(ctx, ctrl && keep && ((uintptr_t)keep % 256) == 0, "ddsp_unit2ctrl_fwd_keep: null ctrl / keep, or keep not 256-byte aligned");
+    DDSP_REQUIRE(ctx, !wp->causal, "ddsp_unit2ctrl_fwd_keep: the causal network (c: true) is built for inference only");
+    if ((rc = ddsp_take_dev_error(ctx))) return rc;
+    if (B == 0) return DDSP_OK;
+    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    U2CBufs bf;
+    Arena k{ctx, false, 0, 0, (char*)keep, (size_t)keep_bytes};
+    plan_forward(k, bf, *wp, B, Fr, true);
+    DDSP_REQUIRE(ctx, !k.rc, "ddsp_unit2ctrl_fwd_keep: keep_bytes is smaller than ddsp_unit2ctrl_keep_bytes says");
+    return u2c_forward(ctx, (hipStream_t)stream, *wp, in, bf, ctrl);
+}
+
+extern "C" int ddsp_unit2ctrl_bwd_kept(ddsp_ctx* ctx, void* stream, const ddsp_u2c_weights* wp, const float* units,
+                                       const float* f0_frames, const float* phase_frames, const float* volume,
+                                       const int64_t* spk_id, int64_t n_spk_id, const int64_t* mix_ids_host,
+                                       const float* mix_w_host, int n_mix, int64_t B, int64_t Fr, void* keep,
+                                       int64_t keep_bytes, const float* d_ctrl, const ddsp_u2c_weights* grads_host) {
+    U2CInputs in;
+    int rc = check_inputs(ctx, wp, units, f0_frames, phase_frames, volume, spk_id, n_spk_id, mix_ids_host, mix_w_host,
+                          n_mix, B, Fr, in);
+    if (rc) return rc;
+    DDSP_REQUIRE(ctx, d_ctrl && grads_host && keep && ((uintptr_t)keep % 256) == 0, "ddsp_unit2ctrl_bwd_kept: null argument or keep not 256-byte aligned");
+    DDSP_REQUIRE(ctx, !wp->causal, "ddsp_unit2ctrl_bwd_kept: the causal network (c: true) is built for inference only");
+    if ((rc = ddsp_take_dev_error(ctx))) return rc;
+    if (B == 0) return DDSP_OK;
+    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    return u2c_backward(ctx, (hipStream_t)stream, *wp, *grads_host, in, B, Fr, d_ctrl, nullptr, keep, (size_t)keep_bytes);
 }

@@ -179,10 +179,11 @@ class Unit2Control(nn.Module):
                 ("head_g", head.weight_g), ("head_v", head.weight_v), ("head_b", head.bias)]
         return out
 
-    def backward_flat(self, units, f0, phase, volume, spk_id, spk_mix_dict, d_ctrl, ctx=None):
+    def backward_flat(self, units, f0, phase, volume, spk_id, spk_mix_dict, d_ctrl, ctx=None, kept=None):
         """Gradients of every parameter for an upstream d_ctrl (B,Fr,n_out): {parameter tensor: gradient tensor}.
         `ctx`: the context of the forward call (autograd runs backward on its own thread; reusing the forward's
-        context keeps one scratch arena and one profiler per model call)."""
+        context keeps one scratch arena and one profiler per model call).  `kept`: the activation region of a
+        `forward_flat_keep` call on the same inputs and weights - without it the forward is re-run inside the call."""
         if self.causal:
             raise NotImplementedError("the causal network (c: true) is built for inference only")
         ctx = ctx or hipddsp.context_for(units.device)
@@ -204,7 +205,10 @@ class Unit2Control(nn.Module):
             grads[t] = gt
             setattr(g, name, gt.data_ptr())
         g.n_spk, g.n_unit, g.n_out = self.n_spk, self.n_unit, self.n_out
-        ctx.unit2ctrl_bwd(w, g, units, f0, phase, volume, spk_id, spk_mix_dict, self.n_out, d_ctrl)
+        if kept is not None:
+            ctx.unit2ctrl_bwd_kept(w, g, units, f0, phase, volume, spk_id, spk_mix_dict, kept, d_ctrl)
+        else:
+            ctx.unit2ctrl_bwd(w, g, units, f0, phase, volume, spk_id, spk_mix_dict, self.n_out, d_ctrl)
         return grads
 
     def _weights_struct(self):
@@ -250,6 +254,16 @@ class Unit2Control(nn.Module):
         ctx = hipddsp.context_for(units.device)
         w, keep = self._weights_struct()
         return ctx.unit2ctrl(w, units, f0, phase, volume, spk_id, spk_mix_dict, self.n_out)
+
+    def forward_flat_keep(self, units, f0, phase, volume, spk_id, spk_mix_dict=None, ctx=None):
+        """Training forward: (control matrix, kept activations) - PyTorch keeps a module's activations for `backward`
+        (reference `solver.py:111-113`); here the library leaves them in one device region that `backward_flat(kept=...)`
+        starts from, so the network runs once per step."""
+        if self.causal:
+            raise NotImplementedError("the causal network (c: true) is built for inference only")
+        ctx = ctx or hipddsp.context_for(units.device)
+        w, keep = self._weights_struct()
+        return ctx.unit2ctrl_keep(w, units, f0, phase, volume, spk_id, spk_mix_dict, self.n_out)
 
     def forward(self, units, f0, phase, volume, spk_id, spk_mix_dict=None):
         """Same contract as the reference `Unit2Control.forward` (`ddsp/unit2control.py:68-101`):

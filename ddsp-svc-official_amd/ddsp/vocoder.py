@@ -154,14 +154,15 @@ class _SynthTrainFn(torch.autograd.Function):
         keep_math = ctx.math
         ctx.set_math(hipddsp.MATH_FP32)
         try:
-            ctrl = model.unit2ctrl.forward_flat(units, f0_frames, ps["phase_frames"], volume, spk_id, spk_mix_dict)
+            ctrl, kept = model.unit2ctrl.forward_flat_keep(units, f0_frames, ps["phase_frames"], volume, spk_id,
+                                                           spk_mix_dict, ctx=ctx)
             nargs = model._noise_args(noise, noise_seed)
             outs, saved = model._train_forward(ctx, ctrl, ps, f0_frames, nargs)
         finally:
             ctx.set_math(keep_math)
         fctx.model, fctx.dsp = model, ctx
         fctx.args = (units, f0_frames, volume, spk_id, spk_mix_dict, nargs, ps["phase_frames"])
-        fctx.saved = (ctrl, saved)
+        fctx.saved = (ctrl, saved, kept)
         phase_out = ps["phase"] if model._front_wants.get("want_phase") else ps["phase_frames"]
         fctx.mark_non_differentiable(phase_out)
         return (phase_out,) + tuple(outs)
@@ -170,11 +171,13 @@ class _SynthTrainFn(torch.autograd.Function):
     def backward(fctx, d_phase, *d_outs):
         model, ctx = fctx.model, fctx.dsp
         units, f0_frames, volume, spk_id, spk_mix_dict, nargs, phase_frames = fctx.args
-        ctrl, saved = fctx.saved
+        if fctx.saved is None:
+            raise RuntimeError("this synthesiser forward was already back-propagated (its kept activations are released)")
+        ctrl, saved, kept = fctx.saved
         B, Fr = ctrl.shape[0], ctrl.shape[1]
         d_ctrl = model._train_backward(ctx, ctrl, saved, f0_frames, nargs, d_outs)
         grads = model.unit2ctrl.backward_flat(units, f0_frames, phase_frames, volume, spk_id, spk_mix_dict,
-                                              d_ctrl.reshape(B, Fr, -1), ctx=ctx)
+                                              d_ctrl.reshape(B, Fr, -1), ctx=ctx, kept=kept)
         fctx.saved = None
         return (None,) * 10 + tuple(grads.get(p) for p in model.unit2ctrl.parameters())
 

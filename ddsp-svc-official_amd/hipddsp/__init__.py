@@ -93,6 +93,12 @@ SIGNATURES = {
     "ddsp_unit2ctrl_bwd": (_int, [_vp, _vp, _c.POINTER(U2CWeights), _vp, _vp, _vp, _vp, _vp, _i64,
                                   _c.POINTER(_i64), _c.POINTER(_f32), _int, _i64, _i64, _vp, _c.POINTER(U2CWeights), _vp]),
     "ddsp_ltv_fir": (_int, [_vp, _vp, _vp, _int, _u64, _vp, _i64, _i64, _int, _int, _vp, _vp, _vp, _int]),
+    "ddsp_unit2ctrl_keep_bytes": (_i64, [_c.POINTER(U2CWeights), _i64, _i64]),
+    "ddsp_unit2ctrl_fwd_keep": (_int, [_vp, _vp, _c.POINTER(U2CWeights), _vp, _vp, _vp, _vp, _vp, _i64,
+                                       _c.POINTER(_i64), _c.POINTER(_f32), _int, _i64, _i64, _vp, _i64, _vp]),
+    "ddsp_unit2ctrl_bwd_kept": (_int, [_vp, _vp, _c.POINTER(U2CWeights), _vp, _vp, _vp, _vp, _vp, _i64,
+                                       _c.POINTER(_i64), _c.POINTER(_f32), _int, _i64, _i64, _vp, _i64, _vp,
+                                       _c.POINTER(U2CWeights)]),
 }
 
 _lib = None
@@ -287,6 +293,46 @@ class Context:
         self.call("ddsp_unit2ctrl_bwd", ctypes.byref(weights), _ptr(units), _ptr(f0), _ptr(ph), _ptr(vol), _ptr(sid),
                   n_sid, ids, ws, n_mix, B, Fr, _ptr(d_ctrl), ctypes.byref(grads), _ptr(ctrl))
         return ctrl
+
+    def _u2c_inputs(self, units, f0_frames, phase_frames, volume, spk_id, spk_mix_dict):
+        B, Fr, _ = units.shape
+        dev = units.device
+        units = units.contiguous().float()
+        f0 = f0_frames.reshape(B, Fr).contiguous().float()
+        ph = phase_frames.reshape(B, Fr).contiguous().float()
+        vol = volume.reshape(B, Fr).contiguous().float()
+        if spk_mix_dict is not None:
+            n_mix = len(spk_mix_dict)
+            ids = (_i64 * max(n_mix, 1))(*[int(k) for k in spk_mix_dict.keys()])
+            ws = (_f32 * max(n_mix, 1))(*[float(v) for v in spk_mix_dict.values()])
+            sid, n_sid = None, 0
+        else:
+            n_mix, ids, ws = 0, None, None
+            sid = spk_id.reshape(-1).to(device=dev, dtype=torch.int64).contiguous()
+            n_sid = sid.numel()
+            if n_sid not in (1, B):
+                raise ValueError(f"spk_id must hold 1 or B={B} ids, got {n_sid}")
+        return (units, f0, ph, vol, sid), (_ptr(units), _ptr(f0), _ptr(ph), _ptr(vol), _ptr(sid), n_sid, ids, ws, n_mix, B, Fr)
+
+    def unit2ctrl_keep(self, weights, units, f0_frames, phase_frames, volume, spk_id, spk_mix_dict, n_out):
+        """Training forward (fp32 products) that keeps its activations: -> (ctrl (B,Fr,n_out), keep) where `keep` is the
+        uint8 device tensor `unit2ctrl_bwd_kept` back-propagates from (the caller holds it until then)."""
+        B, Fr, _ = units.shape
+        nbytes = int(self.lib.ddsp_unit2ctrl_keep_bytes(ctypes.byref(weights), B, Fr))
+        if nbytes < 0:
+            raise ValueError("ddsp_unit2ctrl_keep_bytes: bad shape")
+        keep = torch.empty(nbytes, device=units.device, dtype=torch.uint8)
+        ctrl = torch.empty(B, Fr, n_out, device=units.device, dtype=torch.float32)
+        hold, args = self._u2c_inputs(units, f0_frames, phase_frames, volume, spk_id, spk_mix_dict)
+        self.call("ddsp_unit2ctrl_fwd_keep", ctypes.byref(weights), *args, _ptr(keep), nbytes, _ptr(ctrl))
+        return ctrl, keep
+
+    def unit2ctrl_bwd_kept(self, weights, grads, units, f0_frames, phase_frames, volume, spk_id, spk_mix_dict, keep, d_ctrl):
+        """Back-propagates d_ctrl from the activations `unit2ctrl_keep` left in `keep` (no second forward)."""
+        d_ctrl = d_ctrl.contiguous().float()
+        hold, args = self._u2c_inputs(units, f0_frames, phase_frames, volume, spk_id, spk_mix_dict)
+        self.call("ddsp_unit2ctrl_bwd_kept", ctypes.byref(weights), *args, _ptr(keep), keep.numel(), _ptr(d_ctrl),
+                  ctypes.byref(grads))
 
     # -- a5-a6 ---------------------------------------------------------------------------------
     def fir_from_ctrl(self, mode, ctrl2d, col0, n_mag, rows, sr, f0_frames=None):

@@ -156,6 +156,23 @@ int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_weights* weig
                        const float* mix_w_host, int n_mix, int64_t B, int64_t Fr, const float* d_ctrl,
                        const ddsp_u2c_weights* grads_host, float* ctrl_out);
 
+/* A training step without the second forward: ddsp_unit2ctrl_fwd_keep is ddsp_unit2ctrl_fwd in fp32 products that leaves
+ * its activations (~40 KB per frame and layer) in `keep`, a caller-owned device region of ddsp_unit2ctrl_keep_bytes(w, B, Fr)
+ * bytes, 256-byte aligned (the autograd node owns it between the two calls: reference `solver.py:111-113`, where PyTorch
+ * keeps the activations); ddsp_unit2ctrl_bwd_kept back-propagates from them exactly like ddsp_unit2ctrl_bwd, which re-runs
+ * the forward instead.  The weights must not change between the two calls. */
+int64_t ddsp_unit2ctrl_keep_bytes(const ddsp_u2c_weights* w, int64_t B, int64_t Fr);
+int ddsp_unit2ctrl_fwd_keep(ddsp_ctx* ctx, void* stream, const ddsp_u2c_weights* w, const float* units,
+                            const float* f0_frames, const float* phase_frames, const float* volume,
+                            const int64_t* spk_id, int64_t n_spk_id, const int64_t* mix_ids_host,
+                            const float* mix_w_host, int n_mix, int64_t B, int64_t Fr, void* keep, int64_t keep_bytes,
+                            float* ctrl);
+int ddsp_unit2ctrl_bwd_kept(ddsp_ctx* ctx, void* stream, const ddsp_u2c_weights* w, const float* units,
+                            const float* f0_frames, const float* phase_frames, const float* volume,
+                            const int64_t* spk_id, int64_t n_spk_id, const int64_t* mix_ids_host,
+                            const float* mix_w_host, int n_mix, int64_t B, int64_t Fr, void* keep, int64_t keep_bytes,
+                            const float* d_ctrl, const ddsp_u2c_weights* grads_host);
+
 /* ---- backward of a5-a8 (training: reference autograd through frequency_filter, solver.py:113) ------------ */
 /* Adjoints of ddsp_ltv_fir for an upstream gradient d_out (B,T): d_audio (B,T) or NULL = gradient w.r.t. the
  * input signal; d_ir (B,Fr,n) or NULL = gradient w.r.t. the filter frames (needs the forward input: audio with

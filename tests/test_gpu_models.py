@@ -387,7 +387,7 @@ def test_speaker_id_out_of_range_is_reported(dev, lib_path):
     with pytest.raises(ValueError, match="spk_id"):
         model(d["units"], d["f0"], d["volume"], d["spk_id"], noise=d["noise"])
     # backward: no write outside the gradient table.  The id is changed between forward and backward (the node keeps the
-    # caller's tensor), so that the recomputed forward inside ddsp_unit2ctrl_bwd and the table-gradient kernel meet it
+    # caller's tensor), so that the table-gradient kernel meets it
     model.train()
     ids = d["spk_id"].clone()
     sig = model(d["units"], d["f0"], d["volume"], ids, infer=False, noise=d["noise"])[0]
