@@ -1,5 +1,6 @@
 // Shared host/device helpers for libddsp_amd (gfx950 only).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -67,6 +68,37 @@ static inline int ddsp_fail(ddsp_ctx* ctx, int code, const char* what, const cha
     do {                                                                        \
         hipError_t e_ = (call);                                                 \
         if (e_ != hipSuccess) return ddsp_fail(ctx, DDSP_ERR_HIP, #call, hipGetErrorString(e_)); \
+    } while (0)
+
+// The calling thread's current device is changed only for the duration of a library call: DDSP_ENTER_DEVICE
+// selects the context's device and the guard's destructor restores the caller's when the function returns.
+struct ddsp_device_guard {
+    int prev = -1;
+    bool changed = false;
+    hipError_t enter(int dev) {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) return e;
+        if (prev == dev) return hipSuccess;
+        e = hipSetDevice(dev);
+        changed = (e == hipSuccess);
+        return e;
+    }
+    ~ddsp_device_guard() {
+        if (changed) (void)hipSetDevice(prev);
+    }
+};
+#define DDSP_ENTER_DEVICE(ctx)   \
+    ddsp_device_guard dev_guard_; \
+    DDSP_HIP(ctx, dev_guard_.enter((ctx)->device))
+// hipFuncSetAttribute and its like are per device: run `...` once for each device a context of this process lives on
+#define DDSP_ONCE_PER_DEVICE(ctx, ...)                                                   \
+    do {                                                                                 \
+        static std::atomic<uint64_t> done_{0};                                           \
+        const uint64_t bit_ = 1ull << ((ctx)->device & 63);                              \
+        if (!(done_.load(std::memory_order_acquire) & bit_)) {                           \
+            __VA_ARGS__;                                                                 \
+            done_.fetch_or(bit_, std::memory_order_release);                             \
+        }                                                                                \
     } while (0)
 
 #define DDSP_REQUIRE(ctx, cond, msg)                                            \

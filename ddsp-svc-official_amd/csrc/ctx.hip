@@ -29,7 +29,8 @@ extern "C" int ddsp_ctx_create(ddsp_ctx** out, int device) {
 
 extern "C" int ddsp_ctx_destroy(ddsp_ctx* ctx) {
     if (!ctx) return DDSP_OK;
-    (void)hipSetDevice(ctx->device);
+    ddsp_device_guard guard;
+    (void)guard.enter(ctx->device);
     (void)hipDeviceSynchronize();
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->packed) (void)hipFree(ctx->packed);
@@ -63,7 +64,7 @@ extern "C" const char* ddsp_last_error(const ddsp_ctx* ctx) { return ctx ? ctx->
 int ddsp_scratch_reserve_bytes(ddsp_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->scratch_bytes) return DDSP_OK;
     // Growing: earlier kernels may still read the old arena, so drain the device first.
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     DDSP_HIP(ctx, hipDeviceSynchronize());
     if (ctx->scratch) DDSP_HIP(ctx, hipFree(ctx->scratch));
     ctx->scratch = nullptr;
@@ -168,7 +169,7 @@ extern "C" int ddsp_profile_end(ddsp_ctx* ctx, ddsp_prof_entry* out, int max_ent
 
 int ddsp_dev_error_ptr(ddsp_ctx* ctx, int** out) {
     if (!ctx->dev_error_host) {
-        DDSP_HIP(ctx, hipSetDevice(ctx->device));
+        DDSP_ENTER_DEVICE(ctx);
         int* h = nullptr;
         hipError_t e = hipHostMalloc((void**)&h, 64, hipHostMallocMapped);
         if (e != hipSuccess) return ddsp_fail(ctx, DDSP_ERR_OOM, "error flag hipHostMalloc", hipGetErrorString(e));
@@ -203,7 +204,7 @@ extern "C" int ddsp_ctx_poll_error(ddsp_ctx* ctx) {
 
 int ddsp_zero_page(ddsp_ctx* ctx, const float** out) {
     if (!ctx->zero_page) {
-        DDSP_HIP(ctx, hipSetDevice(ctx->device));
+        DDSP_ENTER_DEVICE(ctx);
         float* p = nullptr;
         hipError_t e = hipMalloc((void**)&p, DDSP_ZERO_FLOATS * sizeof(float));
         if (e != hipSuccess) return ddsp_fail(ctx, DDSP_ERR_OOM, "zero page hipMalloc", hipGetErrorString(e));

@@ -191,7 +191,7 @@ extern "C" int ddsp_fir_from_ctrl(ddsp_ctx* ctx, void* stream, int mode, const f
     DDSP_REQUIRE(ctx, mode != DDSP_FIR_DYNAMIC || f0_frames, "ddsp_fir_from_ctrl: DYNAMIC needs f0_frames");
     if (rows == 0) return DDSP_OK;
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     const int M = n_mag, n = 2 * (n_mag - 1);
     const int K = (mode == DDSP_FIR_ALLPASS) ? 2 * M : M;
     const int lda = ddsp_pad4(K);
@@ -261,7 +261,7 @@ extern "C" int ddsp_fir_from_ctrl_bwd(ddsp_ctx* ctx, void* stream, int mode, con
     DDSP_REQUIRE(ctx, mode != DDSP_FIR_DYNAMIC || f0_frames, "ddsp_fir_from_ctrl_bwd: DYNAMIC needs f0_frames");
     if (rows == 0) return DDSP_OK;
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     const int M = n_mag, n = 2 * (n_mag - 1);
     const int K = (mode == DDSP_FIR_ALLPASS) ? 2 * M : M;
     const int lda = ddsp_pad4(K);

@@ -59,7 +59,7 @@ extern "C" int ddsp_volume_extract(ddsp_ctx* ctx, void* stream, const float* aud
     DDSP_REQUIRE(ctx, T > (hop + 1) / 2, "ddsp_volume_extract: signal shorter than the reflect padding");
     if (B == 0) return DDSP_OK;
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     const int64_t n_frames = T / hop + 1, total = B * n_frames;
     ddsp_prof_begin(ctx, st, PF_OTHER);
     hipLaunchKernelGGL(volume_kernel, dim3((unsigned)ceil_div64(total, 4)), dim3(256), 0, st, audio, T, hop, n_frames, total,
@@ -76,7 +76,7 @@ extern "C" int ddsp_align_units(ddsp_ctx* ctx, void* stream, const float* units,
                  "ddsp_align_units: bad shape or ratio");
     if (B == 0 || n_frames == 0) return DDSP_OK;
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     const int64_t total = B * n_frames;
     ddsp_prof_begin(ctx, st, PF_OTHER);
     hipLaunchKernelGGL(align_units_kernel, dim3((unsigned)ceil_div64(total, 4)), dim3(256), 0, st, units, Lu, C, n_frames,

@@ -7,7 +7,7 @@ extern "C" int ddsp_gemm_f32(ddsp_ctx* ctx, void* stream, const float* A, int64_
     DDSP_REQUIRE(ctx, ctx && A && B && C, "ddsp_gemm_f32: null argument");
     DDSP_REQUIRE(ctx, M >= 1 && N >= 1 && K >= 1 && lda >= 1 && ldb >= 1 && ldc >= N, "ddsp_gemm_f32: bad shape");
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     gemm::Args g = gemm::make(A, lda, B, ldb, M, N, K);
     gemm::EpiStore e{C, ldc, bias, 1, 0, 0};
     ddsp_prof_begin(ctx, st, PF_OTHER);

@@ -630,12 +630,7 @@ __global__ void __launch_bounds__(64 * (2 + SW) * SEGB) ltv_fir_bf16_march_kerne
 
 template <int SEGB>
 int launch_fir_bf16(ddsp_ctx* ctx, hipStream_t st, FirBfArgs g, int64_t B, int64_t Fr, size_t lds_bytes) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        DDSP_HIP(ctx, hipFuncSetAttribute((const void*)ltv_fir_bf16_kernel<SEGB>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    DDSP_ONCE_PER_DEVICE(ctx, DDSP_HIP(ctx, hipFuncSetAttribute((const void*)ltv_fir_bf16_kernel<SEGB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
     dim3 grid((unsigned)((Fr + SEGB - 1) / SEGB), (unsigned)B);
     hipLaunchKernelGGL((ltv_fir_bf16_kernel<SEGB>), grid, dim3(64 * 2 * SEGB), lds_bytes, st, g);
     return DDSP_OK;
@@ -643,12 +638,7 @@ int launch_fir_bf16(ddsp_ctx* ctx, hipStream_t st, FirBfArgs g, int64_t B, int64
 
 template <int SEGB, int SW, bool PAIR>
 int launch_fir_bf16_march(ddsp_ctx* ctx, hipStream_t st, FirBfArgs g, int64_t B, int nchunks, size_t lds_bytes) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        DDSP_HIP(ctx, hipFuncSetAttribute((const void*)ltv_fir_bf16_march_kernel<SEGB, SW, PAIR>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    DDSP_ONCE_PER_DEVICE(ctx, DDSP_HIP(ctx, hipFuncSetAttribute((const void*)ltv_fir_bf16_march_kernel<SEGB, SW, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
     hipLaunchKernelGGL((ltv_fir_bf16_march_kernel<SEGB, SW, PAIR>), dim3((unsigned)nchunks, (unsigned)B),
                        dim3(64 * (2 + SW) * SEGB), lds_bytes, st, g);
     return DDSP_OK;
@@ -859,7 +849,7 @@ extern "C" int ddsp_ltv_fir(ddsp_ctx* ctx, void* stream, const float* audio, int
         const size_t per_frame = (size_t)(4 * g.fd + 2 * XPLANE) * sizeof(uint32_t);
         g.chunk = 0;
         g.ring = 0;
-        DDSP_HIP(ctx, hipSetDevice(ctx->device));
+        DDSP_ENTER_DEVICE(ctx);
         // (a) marching blocks when every CU can own a long run of segments: block shape by LDS, <segments per step,
         //     staging waves per frame>.  math 41..44 force a shape (tools/fir_bf16_check.py).
         {
@@ -962,13 +952,8 @@ extern "C" int ddsp_ltv_fir(ddsp_ctx* ctx, void* stream, const float* audio, int
     g.irs = (n + 2 * IRPAD + 3) & ~3;
     const size_t lds_bytes = (size_t)g.nfr * (g.irs + XS) * sizeof(float);
     DDSP_REQUIRE(ctx, lds_bytes <= 160 * 1024, "ddsp_ltv_fir: filter too long for the LDS staging");
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
-    static bool attr_set = false;
-    if (!attr_set) {
-        DDSP_HIP(ctx, hipFuncSetAttribute((const void*)ltv_fir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          160 * 1024));
-        attr_set = true;
-    }
+    DDSP_ENTER_DEVICE(ctx);
+    DDSP_ONCE_PER_DEVICE(ctx, DDSP_HIP(ctx, hipFuncSetAttribute((const void*)ltv_fir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
     dim3 grid((unsigned)((Fr + SEG - 1) / SEG), (unsigned)B);
     ddsp_prof_begin(ctx, (hipStream_t)stream, PF_LTV_FIR);
     hipLaunchKernelGGL(ltv_fir_kernel, grid, dim3(64 * 2 * SEG), lds_bytes, (hipStream_t)stream, g);
@@ -989,13 +974,8 @@ extern "C" int ddsp_ltv_fir_bwd(ddsp_ctx* ctx, void* stream, const float* audio,
     DDSP_REQUIRE(ctx, ((uintptr_t)d_out % 16) == 0 && ((uintptr_t)d_audio % 16) == 0, "ddsp_ltv_fir_bwd: d_out/d_audio must be 16-byte aligned");
     if (B == 0) return DDSP_OK;
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
-    static bool attr_set = false;
-    if (!attr_set) {
-        DDSP_HIP(ctx, hipFuncSetAttribute((const void*)ltv_fir_bwd_input_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DDSP_HIP(ctx, hipFuncSetAttribute((const void*)ltv_fir_bwd_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    DDSP_ENTER_DEVICE(ctx);
+    DDSP_ONCE_PER_DEVICE(ctx, DDSP_HIP(ctx, hipFuncSetAttribute((const void*)ltv_fir_bwd_input_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); DDSP_HIP(ctx, hipFuncSetAttribute((const void*)ltv_fir_bwd_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
     const double Ts = (double)Fr * HOP;
     if (d_audio) {
         FirBwdInArgs g;

@@ -148,7 +148,7 @@ extern "C" int ddsp_conv1d(ddsp_ctx* ctx, void* stream, const float* x, const fl
                  "ddsp_conv1d: bad shape (Cin % 4 == 0, odd tap count)");
     DDSP_REQUIRE(ctx, x != out, "ddsp_conv1d: in-place convolution is not possible");
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     gemm::Args g = gemm::make(x, Cin, w_packed, (int64_t)ktaps * Cin, (int)T, Cout, ktaps * Cin);
     g.Fr = (int)T;
     g.Cin = Cin;
@@ -171,7 +171,7 @@ extern "C" int ddsp_nsf_source(ddsp_ctx* ctx, void* stream, const float* f0, con
     DDSP_REQUIRE(ctx, ctx && f0 && rand_ini && lin_w && lin_b && out, "ddsp_nsf_source: null argument");
     DDSP_REQUIRE(ctx, L >= 1 && L < (1 << 24) && upp >= 1 && upp <= 65536 && sr >= 1, "ddsp_nsf_source: bad shape");
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     int rc = ddsp_scratch_reserve_bytes(ctx, (size_t)L * NH * sizeof(double) + 4096);
     if (rc) return rc;
     ddsp_scratch_reset(ctx);
@@ -192,7 +192,7 @@ extern "C" int ddsp_nsf_noise_conv(ddsp_ctx* ctx, void* stream, const float* src
                  "ddsp_nsf_noise_conv: bad shape");
     DDSP_REQUIRE(ctx, (T_out - 1) * stride - pad < T_src, "ddsp_nsf_noise_conv: output longer than the source allows");
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     hipLaunchKernelGGL(nsf_noise_conv_kernel, dim3((unsigned)((T_out * C + 255) / 256)), dim3(256), 0, st, src, T_src, w, b, T_out,
                        C, K, stride, pad, out);
     DDSP_LAUNCH_CHECK(ctx);
@@ -204,7 +204,7 @@ extern "C" int ddsp_nsf_post(ddsp_ctx* ctx, void* stream, const float* x, const 
     DDSP_REQUIRE(ctx, ctx && x && w && b && out, "ddsp_nsf_post: null argument");
     DDSP_REQUIRE(ctx, T >= 1 && C >= 1 && K >= 1 && K % 2 == 1, "ddsp_nsf_post: bad shape");
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     hipLaunchKernelGGL(nsf_post_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, x, w, b, T, C, K, slope, out);
     DDSP_LAUNCH_CHECK(ctx);
     return DDSP_OK;
@@ -216,7 +216,7 @@ extern "C" int ddsp_nsf_mean(ddsp_ctx* ctx, void* stream, const float* a, const 
                  "ddsp_nsf_mean: bad argument");
     if (n == 0) return DDSP_OK;
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     int64_t blocks = (n + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(nsf_mean_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, b, c, n_terms, n, out);
@@ -232,7 +232,7 @@ extern "C" int ddsp_log_mel(ddsp_ctx* ctx, void* stream, const float* frames, co
     DDSP_REQUIRE(ctx, n_frames >= 1 && n_frames < (1 << 24) && n_fft >= 4 && n_fft % 4 == 0 && n_mels >= 1,
                  "ddsp_log_mel: bad shape");
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     const int bins = n_fft / 2 + 1, ldm = (bins + 3) & ~3, lds = 2 * ldm;
     int rc = ddsp_scratch_reserve_bytes(ctx, (size_t)n_frames * (lds + ldm) * sizeof(float) + 8192);
     if (rc) return rc;

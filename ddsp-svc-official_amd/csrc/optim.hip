@@ -70,7 +70,7 @@ extern "C" int ddsp_adamw_step_multi(ddsp_ctx* ctx, void* stream, int n_tensors,
     if (n_tensors == 0) return DDSP_OK;
     DDSP_REQUIRE(ctx, params && grads && exp_avg && exp_avg_sq && numel, "ddsp_adamw_step_multi: null table");
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     double total = 0;
@@ -121,7 +121,7 @@ extern "C" int ddsp_adamw_step(ddsp_ctx* ctx, void* stream, float* param, const 
     DDSP_REQUIRE(ctx, n >= 0 && step >= 1, "ddsp_adamw_step: bad size or step");
     if (n == 0) return DDSP_OK;
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     int64_t blocks = ceil_div64(n, 256);

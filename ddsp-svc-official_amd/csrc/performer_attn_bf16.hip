@@ -554,7 +554,7 @@ extern "C" int ddsp_performer_attention(ddsp_ctx* ctx, void* stream, const float
     if (math >= 100) math = DDSP_MATH_SPLIT_BF16;
     DDSP_REQUIRE(ctx, math == DDSP_MATH_FP32 || math == DDSP_MATH_SPLIT_BF16, "ddsp_performer_attention: unknown math");
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     const size_t n_cx = (size_t)B * H * (PERFORMER_CTXS_FLOATS > PERFORMER_LDJ * DH ? PERFORMER_CTXS_FLOATS : PERFORMER_LDJ * DH);
     const size_t n_ks = (size_t)B * H * PERFORMER_KS_STRIDE;
     int rc = ddsp_scratch_reserve_bytes(ctx, (n_cx + n_ks) * sizeof(float) + PERFORMER_P3_BYTES + 4096);

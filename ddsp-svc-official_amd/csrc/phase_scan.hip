@@ -215,6 +215,7 @@ extern "C" int ddsp_upsample(ddsp_ctx* ctx, void* stream, const float* x, int64_
     DDSP_REQUIRE(ctx, B >= 0 && Fr >= 1 && C >= 1 && hop >= 1, "ddsp_upsample: bad shape");
     DDSP_REQUIRE(ctx, Fr * (int64_t)hop < (1 << 24), "ddsp_upsample: Fr*hop must stay below 2^24 (fp32 index grid)");
     if (B == 0) return DDSP_OK;
+    DDSP_ENTER_DEVICE(ctx);
     const float scale = (float)Fr / (float)(Fr * hop);
     const int64_t total = B * Fr * hop * C;
     int64_t blocks = ceil_div64(total, 256);
@@ -236,7 +237,7 @@ extern "C" int ddsp_phase_scan(ddsp_ctx* ctx, void* stream, const float* f0_fram
     if (B == 0) return DDSP_OK;
     hipStream_t st = (hipStream_t)stream;
     const int64_t nf = B * Fr;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     int rc = ddsp_scratch_reserve_bytes(ctx, (size_t)nf * sizeof(double) + 4096);
     if (rc) return rc;
     ddsp_scratch_reset(ctx);

@@ -179,7 +179,7 @@ extern "C" int ddsp_phase_vocoder(ddsp_ctx* ctx, void* stream, const float* a, c
     DDSP_REQUIRE(ctx, ctx && a && b && fade_out && fade_in && out, "ddsp_phase_vocoder: null argument");
     DDSP_REQUIRE(ctx, n >= 2 && n <= (1 << 16), "ddsp_phase_vocoder: bad length");
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     const int F = n / 2 + 1;
     int rc = ddsp_scratch_reserve_bytes(ctx, (size_t)3 * F * sizeof(float) + 4096);
     if (rc) return rc;
@@ -201,7 +201,7 @@ extern "C" int ddsp_sola(ddsp_ctx* ctx, void* stream, const float* audio, int64_
     DDSP_REQUIRE(ctx, block >= xfade && xfade >= 1 && search >= 0 && delay >= 1, "ddsp_sola: bad sizes");
     DDSP_REQUIRE(ctx, n_audio >= (int64_t)block + xfade + search + delay, "ddsp_sola: window shorter than block+xfade+search+delay");
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     int rc = ddsp_scratch_reserve_bytes(ctx, (size_t)(search + 1) * sizeof(float) + 4096);
     if (rc) return rc;
     ddsp_scratch_reset(ctx);
@@ -224,7 +224,7 @@ extern "C" int ddsp_volume_gate(ddsp_ctx* ctx, void* stream, float* signal, cons
     DDSP_REQUIRE(ctx, B >= 0 && Fr >= 1 && hop >= 1 && (hop & (hop - 1)) == 0, "ddsp_volume_gate: bad shape");
     if (B == 0) return DDSP_OK;
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     const int64_t total = B * Fr * hop;
     int64_t blocks = ceil_div64(total, 256);
     if (blocks > 4096) blocks = 4096;

@@ -84,7 +84,7 @@ extern "C" int ddsp_resample(ddsp_ctx* ctx, void* stream, const float* x, int64_
                  "ddsp_resample: bad argument");
     if (B == 0) return DDSP_OK;
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     const int g = gcd_int(orig_freq, new_freq);
     const int orig = orig_freq / g, nw = new_freq / g;
     DDSP_REQUIRE(ctx, orig < 65536 && nw < 65536, "ddsp_resample: rate ratio too fine (reduced rates must be < 65536)");

@@ -235,7 +235,7 @@ extern "C" int ddsp_rss_loss(ddsp_ctx* ctx, void* stream, const float* x_pred, c
     }
     if (!grad_pred) tab_f = xp_f = 0;
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     // scratch sized for the worst scale: the two tables, the framed copy of both signals, S_t, S_p, X_p
     int rc = ddsp_scratch_reserve_bytes(ctx, (tabT_f + tab_f + xf_f + 2 * s_f + xp_f) * sizeof(float) +
                                                  (size_t)B * LS_CHUNKS * 3 * sizeof(double) + 16384);

@@ -195,7 +195,7 @@ extern "C" int ddsp_sins_bank(ddsp_ctx* ctx, void* stream, const float* ctrl, in
     DDSP_REQUIRE(ctx, B >= 0 && B <= 65535 && Fr >= 1 && hop >= 1 && (hop & (hop - 1)) == 0, "ddsp_sins_bank: bad shape (hop must be a power of two)");
     if (B == 0) return DDSP_OK;
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     ddsp_prof_begin(ctx, st, PF_SINS_BANK);
     hipLaunchKernelGGL(sins_bank_kernel, dim3((unsigned)Fr, (unsigned)B), dim3(256), 2 * n_harmonics * sizeof(float), st,
                        ctrl, ctrl_ld, n_harmonics, f0_frames, phase, (int)Fr, hop, (float)sr / 2.0f, out);
@@ -215,7 +215,7 @@ extern "C" int ddsp_sins_bank_bwd(ddsp_ctx* ctx, void* stream, const float* ctrl
                  "ddsp_sins_bank_bwd: bad shape (hop must be a power of two <= 1024)");
     if (B == 0) return DDSP_OK;
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     const int64_t rows = B * Fr;
     const size_t pf = (size_t)rows * 2 * n_harmonics;
     int rc = ddsp_scratch_reserve_bytes(ctx, pf * sizeof(float) + 4096);

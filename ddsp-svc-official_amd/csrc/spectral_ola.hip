@@ -248,7 +248,7 @@ extern "C" int ddsp_spectral_ola(ddsp_ctx* ctx, void* stream, const float* ctrl,
                  "ddsp_spectral_ola: excitation must be UNIT_NOISE (with a noise buffer) or GENERATE");
     if (B == 0) return DDSP_OK;
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     const size_t fbytes = (size_t)B * (Fr + 1) * N * sizeof(float);
     int rc = ddsp_scratch_reserve_bytes(ctx, fbytes + 3 * N * sizeof(float) + 8192);
     if (rc) return rc;
@@ -280,7 +280,7 @@ extern "C" int ddsp_spectral_ola_bwd(ddsp_ctx* ctx, void* stream, const float* c
                  "ddsp_spectral_ola_bwd: excitation must be UNIT_NOISE (with a noise buffer) or GENERATE");
     if (B == 0) return DDSP_OK;
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     int rc = ddsp_scratch_reserve_bytes(ctx, 3 * N * sizeof(float) + 8192);
     if (rc) return rc;
     ddsp_scratch_reset(ctx);

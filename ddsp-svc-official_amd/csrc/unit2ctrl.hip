@@ -1182,25 +1182,52 @@ __global__ void __launch_bounds__(256) weight_norm_bwd_kernel(const float* __res
     for (int i = lane; i < n_in; i += 64) dv[(int64_t)o * n_in + i] = s * (dr[i] - proj * vr[i]);
 }
 
-// speaker-embedding gradient: table is zeroed by the caller; per utterance the frame-summed d_x row is added to its
-// speaker's row (atomics: several utterances may share a speaker), or w_k * (sum over everything) in mix mode
-__global__ void __launch_bounds__(256) spk_embed_bwd_kernel(const float* __restrict__ dx, int64_t B, int Fr,
-                                                            const int64_t* __restrict__ spk_id, int64_t n_spk_id,
-                                                            MixArgs mix, float* __restrict__ dtable, int n_spk,
-                                                            int* __restrict__ err) {
-    const int c = threadIdx.x;  // D == 256 channels
+// Gradient of the speaker table, deterministic (no float atomics: the training trajectory is chaotic enough without a
+// run-to-run difference in the last bit).  Pass 1: usum[b][c] = sum_f dx[b,f,c], one block per utterance, 64 lanes x 16
+// bytes across the channels, 16 frame lanes; it also reports an id outside [1, n_spk] (the row is then skipped, like the
+// forward's table read).  Pass 2: one block per table row adds the utterances that use it in ascending order.
+__global__ void __launch_bounds__(1024) utterance_sum_kernel(const float* __restrict__ dx, int Fr,
+                                                             const int64_t* __restrict__ spk_id, int64_t n_spk_id, int n_spk,
+                                                             float* __restrict__ usum, int* __restrict__ err) {
     const int64_t b = blockIdx.x;
-    float s = 0.f;
-    for (int f = 0; f < Fr; ++f) s += dx[((int64_t)b * Fr + f) * D + c];
-    if (mix.n > 0) {
-        for (int k = 0; k < mix.n; ++k) atomicAdd(dtable + (mix.ids[k] - 1) * D + c, mix.w[k] * s);
-    } else {
-        const int64_t id = spk_id[n_spk_id == 1 ? 0 : b];
-        if (id >= 1 && id <= n_spk)
-            atomicAdd(dtable + (id - 1) * D + c, s);
-        else if (c == 0)   // skipped, and reported by the next call / ddsp_ctx_poll_error (like the forward's table read)
-            __hip_atomic_store(err, DDSP_DEV_ERR_SPK_ID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const int c4 = threadIdx.x & 63, fl = threadIdx.x >> 6;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int f = fl; f < Fr; f += 16) s += *(const f32x4*)(dx + ((int64_t)b * Fr + f) * D + 4 * c4);
+    __shared__ f32x4 red[1024];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (fl == 0) {
+        f32x4 t = red[c4];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) t += red[64 * i + c4];
+        *(f32x4*)(usum + b * D + 4 * c4) = t;
     }
+    if (threadIdx.x == 0 && spk_id) {
+        const int64_t id = spk_id[n_spk_id == 1 ? 0 : b];
+        if (id < 1 || id > n_spk) __hip_atomic_store(err, DDSP_DEV_ERR_SPK_ID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+__global__ void __launch_bounds__(256) spk_table_grad_kernel(const float* __restrict__ usum, int64_t B,
+                                                             const int64_t* __restrict__ spk_id, int64_t n_spk_id,
+                                                             MixArgs mix, float* __restrict__ dtable) {
+    const int r = blockIdx.x, c = threadIdx.x;  // D == 256 channels
+    float s = 0.f;
+    if (mix.n > 0) {
+        float cr = 0.f;
+        for (int k = 0; k < mix.n; ++k)
+            if (mix.ids[k] - 1 == r) cr += mix.w[k];
+        if (cr != 0.f) {
+            for (int64_t b = 0; b < B; ++b) s += usum[b * D + c];
+            s *= cr;
+        }
+    } else if (n_spk_id == 1) {
+        if (spk_id[0] - 1 == r)
+            for (int64_t b = 0; b < B; ++b) s += usum[b * D + c];
+    } else {
+        for (int64_t b = 0; b < B; ++b)
+            if (spk_id[b] - 1 == r) s += usum[b * D + c];
+    }
+    dtable[(int64_t)r * D + c] = s;
 }
 
 #define PROF(id, flops, bytes, ...)              \
@@ -1805,7 +1832,7 @@ extern "C" int ddsp_unit2ctrl_fwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
     if ((rc = ddsp_take_dev_error(ctx))) return rc;
     if (B == 0) return DDSP_OK;
     hipStream_t st = (hipStream_t)stream;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     const ddsp_u2c_weights w = *wp;
     U2CBufs bf;
     Arena dry{ctx, true, 0, 0};
@@ -2031,11 +2058,13 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
     }
     DDSP_HIP(ctx, hipMemcpyAsync(G(phase_b), G(f0_b), D * sizeof(float), hipMemcpyDeviceToDevice, st));
     DDSP_HIP(ctx, hipMemcpyAsync(G(volume_b), G(f0_b), D * sizeof(float), hipMemcpyDeviceToDevice, st));
-    DDSP_HIP(ctx, hipMemsetAsync(G(spk_table), 0, (size_t)w.n_spk * D * sizeof(float), st));
     int* dev_err = nullptr;
     if ((rc = ddsp_dev_error_ptr(ctx, &dev_err))) return rc;
-    hipLaunchKernelGGL(spk_embed_bwd_kernel, dim3((unsigned)B), dim3(D), 0, st, dX, B, (int)Fr, in.spk_id, in.n_spk_id,
-                       in.mix, G(spk_table), w.n_spk, dev_err);
+    // (dA is free between the last LayerNorm adjoint and the conv2 input gradient: it holds the per-utterance sums)
+    hipLaunchKernelGGL(utterance_sum_kernel, dim3((unsigned)B), dim3(1024), 0, st, dX, (int)Fr, in.mix.n > 0 ? nullptr : in.spk_id,
+                       in.n_spk_id, w.n_spk, dA, dev_err);
+    hipLaunchKernelGGL(spk_table_grad_kernel, dim3((unsigned)w.n_spk), dim3(D), 0, st, dA, B, in.spk_id, in.n_spk_id, in.mix,
+                       G(spk_table));
     // ---- prenet conv2: weight gradient over the three taps, input gradient as the flipped conv ----
     if ((rc = layer_grads(ctx, st, dX, D, D, bf.t2, D, D, 3, (int)Fr, M, wpart, cpart, xs, pk, 3 * D, G(prenet_conv2_b)))) return rc;
     hipLaunchKernelGGL(unpack_conv3_kernel, dim3(grid_for((int64_t)D * D * 3)), dim3(256), 0, st, pk, D, D, G(prenet_conv2_w));
@@ -2077,7 +2106,7 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
     DDSP_REQUIRE(ctx, !wp->causal, "ddsp_unit2ctrl_bwd: the causal network (c: true) is built for inference only");
     if ((rc = ddsp_take_dev_error(ctx))) return rc;
     if (B == 0) return DDSP_OK;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     return u2c_backward(ctx, (hipStream_t)stream, *wp, *grads_host, in, B, Fr, d_ctrl, ctrl_out, nullptr, 0);
 }
 
@@ -2103,7 +2132,7 @@ extern "C" int ddsp_unit2ctrl_fwd_keep(ddsp_ctx* ctx, void* stream, const ddsp_u
     DDSP_REQUIRE(ctx, !wp->causal, "ddsp_unit2ctrl_fwd_keep: the causal network (c: true) is built for inference only");
     if ((rc = ddsp_take_dev_error(ctx))) return rc;
     if (B == 0) return DDSP_OK;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     U2CBufs bf;
     Arena k{ctx, false, 0, 0, (char*)keep, (size_t)keep_bytes};
     plan_forward(k, bf, *wp, B, Fr, true);
@@ -2124,6 +2153,6 @@ extern "C" int ddsp_unit2ctrl_bwd_kept(ddsp_ctx* ctx, void* stream, const ddsp_u
     DDSP_REQUIRE(ctx, !wp->causal, "ddsp_unit2ctrl_bwd_kept: the causal network (c: true) is built for inference only");
     if ((rc = ddsp_take_dev_error(ctx))) return rc;
     if (B == 0) return DDSP_OK;
-    DDSP_HIP(ctx, hipSetDevice(ctx->device));
+    DDSP_ENTER_DEVICE(ctx);
     return u2c_backward(ctx, (hipStream_t)stream, *wp, *grads_host, in, B, Fr, d_ctrl, nullptr, keep, (size_t)keep_bytes);
 }

@@ -160,7 +160,17 @@ class Context:
 
     # -- helpers ------------------------------------------------------------------------------
     def _stream(self):
-        return torch.cuda.current_stream(self.device).cuda_stream
+        """The torch stream current on this thread.  A context's scratch arena and lazily built tables are ordered by ONE
+        stream (include/ddsp_amd.h: one context per stream); when a caller switches streams under a cached context
+        (`with torch.cuda.stream(s):`), the new stream first waits for everything the context queued on the old one, so a
+        half-built table or a scratch region still being read is never touched.  Concurrency across streams
+        needs a context per stream (`Context(device)` + `use_context`)."""
+        s = torch.cuda.current_stream(self.device)
+        last = getattr(self, "_last_stream", None)
+        if last is not None and last != s and not torch.cuda.is_current_stream_capturing():
+            s.wait_stream(last)
+        self._last_stream = s
+        return s.cuda_stream
 
     def _check(self, rc, what):
         if rc == DDSP_OK:

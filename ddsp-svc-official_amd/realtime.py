@@ -21,13 +21,18 @@ class Splicer:
         self.search = int(search_time * samplerate)
         self.delay = int(delay_time * samplerate)
         self.device = torch.device(device)
-        self.ctx = hipddsp.context_for(self.device)
         self.buffer = torch.zeros(self.xfade, device=self.device)      # `sola_buffer`, gui.py:347
         self.last_shift = None
         # gui.py:349-351 windows, used by the optional phase-vocoder splice (gui.py:417-423)
         self.use_phase_vocoder = bool(use_phase_vocoder)
         self.fade_in = torch.sin(torch.pi * torch.arange(0, 1, 1 / self.xfade, device=self.device)[:self.xfade] / 2) ** 2
         self.fade_out = 1 - self.fade_in
+
+    @property
+    def ctx(self):
+        """The calling thread's context (the audio callback runs on PortAudio's thread, not on the one that built the
+        splicer: each thread gets its own scratch arena)."""
+        return hipddsp.context_for(self.device)
 
     def input_frames(self, buffer_num):
         """Length of the sliding input window (`gui.py:323-325`)."""

@@ -492,3 +492,28 @@ def test_causal_mode_against_reference_fixture(dev, lib_path):
     with pytest.raises((NotImplementedError, ValueError)):
         out = model(d["units"][:1, :8], d["f0"][:1, :8], d["volume"][:1, :8], d["spk_id"][:1], infer=False, noise=d["noise"][:1, :4096])[0]
         out.sum().backward()
+
+
+def test_stream_switch_under_a_cached_context(dev, lib_path):
+    """`context_for` caches one context per (device, thread) while calls launch on the CURRENT torch stream.  A
+    caller that switches streams must not meet a half-built table or a scratch arena another stream still reads: the
+    context makes the new stream wait for what it queued on the old one.  Fresh shapes (so that tables and the arena are
+    (re)built right before the switch), alternating streams, results equal to the single-stream run."""
+    model, cfg = synthetic.build_model("CombSub", seed=9, device=dev)
+    d = _to(synthetic.make_inputs(77, 5, 61), dev)
+    with torch.no_grad():
+        want = model(d["units"], d["f0"], d["volume"], d["spk_id"], noise=d["noise"])[0].clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    outs = []
+    for i in range(4):
+        if i % 2 == 0:
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side), torch.no_grad():
+                outs.append(model(d["units"], d["f0"], d["volume"], d["spk_id"], noise=d["noise"])[0])
+        else:
+            with torch.no_grad():
+                outs.append(model(d["units"], d["f0"], d["volume"], d["spk_id"], noise=d["noise"])[0])
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, want)
