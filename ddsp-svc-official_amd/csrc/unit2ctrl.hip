@@ -571,6 +571,124 @@ __global__ void __launch_bounds__(256) causal_attention_kernel(const float* __re
     }
 }
 
+// ---- backward of the causal attention (training of `c: true` networks; correct first, one frame per step) ------------------
+// With S_n = sum_{m<=n} k'_m (x) v_m, z_n = sum_{m<=n} k'_m, den_n = q'_n.(z_n + 1e-6), out_n = q'_n S_n / den_n and the upstream
+// d_n = dL/d out_n:   dnum_n = d_n / den_n,   dden_n = -(d_n . out_n) / den_n,
+//   dq'_n = S_n dnum_n + dden_n (z_n + 1e-6)                              (forward scan, pass Q)
+//   dk'_n = G_n v_n + g_n,  dv_n = G_n^T k'_n   with G_n = sum_{m>=n} q'_m (x) dnum_m,  g_n = sum_{m>=n} dden_m q'_m   (reverse scans, passes K and V)
+// Passes Q and K: 320 threads, thread j owns row j of the 266 x 64 state (64 registers), so the products with a 64-vector
+// are in-thread; pass V uses the forward kernel's layout (thread (e, r0) owns column e of rows r0 + 4 i), in which the
+// product with a 266-vector is in-thread.  Pass Q also leaves 1/den_n and dden_n for the other two.
+__global__ void __launch_bounds__(320) causal_attn_bwd_q_kernel(const float* __restrict__ qf, const float* __restrict__ kf,
+                                                                const float* __restrict__ v, const float* __restrict__ dout,
+                                                                const float* __restrict__ out, int Fr, float* __restrict__ dqf,
+                                                                float* __restrict__ dinv_out, float* __restrict__ dden_out) {
+    __shared__ float sv[2][DH], sd[2][DH], so[2][DH], red[2][8];
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int t = threadIdx.x;
+    const bool active = t < NF;
+    float S[DH];
+#pragma unroll
+    for (int e = 0; e < DH; ++e) S[e] = 0.f;
+    float z = 0.f;
+    for (int n = 0; n < Fr; ++n) {
+        const int buf = n & 1;
+        const int64_t row = (int64_t)b * Fr + n, row8 = row * H + h;
+        if (t < DH) {
+            sv[buf][t] = v[row * INNER + h * DH + t];
+            sd[buf][t] = dout[row * INNER + h * DH + t];
+            so[buf][t] = out[row * INNER + h * DH + t];
+        }
+        const float qj = active ? qf[row8 * LDF + t] : 0.f, kj = active ? kf[row8 * LDF + t] : 0.f;
+        z += kj;
+        const float dp = wave_sum(qj * (z + 1e-6f));
+        if ((t & 63) == 0) red[buf][t >> 6] = dp;
+        __syncthreads();
+        const float den = ((red[buf][0] + red[buf][1]) + (red[buf][2] + red[buf][3])) + red[buf][4];
+        const float dinv = 1.0f / den;
+        float c = 0.f, acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < DH; ++e) {
+            c = fmaf(sd[buf][e], so[buf][e], c);
+            S[e] = fmaf(kj, sv[buf][e], S[e]);
+            acc = fmaf(S[e], sd[buf][e], acc);
+        }
+        const float dden = -c * dinv;
+        if (active) dqf[row8 * LDF + t] = fmaf(dden, z + 1e-6f, acc * dinv);
+        if (t == 0) {
+            dinv_out[row8] = dinv;
+            dden_out[row8] = dden;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(320) causal_attn_bwd_k_kernel(const float* __restrict__ qf, const float* __restrict__ v,
+                                                                const float* __restrict__ dout, const float* __restrict__ dinv_in,
+                                                                const float* __restrict__ dden_in, int Fr,
+                                                                float* __restrict__ dkf) {
+    __shared__ float sv[2][DH], sd[2][DH];
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int t = threadIdx.x;
+    const bool active = t < NF;
+    float G[DH];
+#pragma unroll
+    for (int e = 0; e < DH; ++e) G[e] = 0.f;
+    float g = 0.f;
+    for (int n = Fr - 1; n >= 0; --n) {
+        const int buf = n & 1;
+        const int64_t row = (int64_t)b * Fr + n, row8 = row * H + h;
+        const float di = dinv_in[row8], dd = dden_in[row8];
+        if (t < DH) {
+            sv[buf][t] = v[row * INNER + h * DH + t];
+            sd[buf][t] = dout[row * INNER + h * DH + t] * di;   // dnum
+        }
+        const float qj = active ? qf[row8 * LDF + t] : 0.f;
+        g = fmaf(dd, qj, g);
+        __syncthreads();
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < DH; ++e) {
+            G[e] = fmaf(qj, sd[buf][e], G[e]);
+            acc = fmaf(G[e], sv[buf][e], acc);
+        }
+        if (active) dkf[row8 * LDF + t] = acc + g;
+    }
+}
+
+__global__ void __launch_bounds__(256) causal_attn_bwd_v_kernel(const float* __restrict__ qf, const float* __restrict__ kf,
+                                                                const float* __restrict__ dout, const float* __restrict__ dinv_in,
+                                                                int Fr, float* __restrict__ dv) {
+    constexpr int ROWS = (NF + 3) / 4;       // 67
+    __shared__ float sq[LDF], sk[LDF], sdn[DH], part[4 * DH];
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int t = threadIdx.x, e = t & 63, r0 = t >> 6;
+    float G[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) G[i] = 0.f;
+    for (int n = Fr - 1; n >= 0; --n) {
+        const int64_t row = (int64_t)b * Fr + n, row8 = row * H + h;
+        for (int j = t; j < LDF; j += 256) {
+            sq[j] = qf[row8 * LDF + j];
+            sk[j] = kf[row8 * LDF + j];
+        }
+        if (t < DH) sdn[t] = dout[row * INNER + h * DH + t] * dinv_in[row8];
+        __syncthreads();
+        const float dne = sdn[e];
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            const int j = r0 + 4 * i;
+            if (j < NF) {
+                G[i] = fmaf(sq[j], dne, G[i]);
+                acc = fmaf(sk[j], G[i], acc);
+            }
+        }
+        part[r0 * DH + e] = acc;
+        __syncthreads();
+        if (t < DH) dv[row * INNER + h * DH + t] = (part[t] + part[DH + t]) + (part[2 * DH + t] + part[3 * DH + t]);
+    }
+}
+
 struct EpiAttnOut {  // out[(b*Fr+n)*512 + h*64 + e] = dinv[(b*Fr+n)*8+h] * acc   (z = b*8+h, m = n, col = e); dinv null -> 1
     float* out;
     const float* dinv;
@@ -893,7 +1011,7 @@ __global__ void __launch_bounds__(256) glu_bwd_kernel(const float* __restrict__ 
 // block = (64 channels, utterance, frame chunk)
 constexpr int DWG_CHUNKS = 4;
 __global__ void __launch_bounds__(256) dwconv_wgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ x,
-                                                           int Fr, float* __restrict__ partial) {
+                                                           int Fr, float* __restrict__ partial, int left) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int tg = threadIdx.x >> 6;  // taps tg, tg+4, ...
     const int b = blockIdx.y, ch = blockIdx.z;
@@ -909,7 +1027,7 @@ __global__ void __launch_bounds__(256) dwconv_wgrad_kernel(const float* __restri
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int t = tg + 4 * i;
-            const int ff = f + t - DWK / 2;
+            const int ff = f + t - left;   // left = DWK / 2: centred taps, DWK - 1: causal taps
             if (t < DWK && ff >= 0 && ff < Fr) acc[i] = fmaf(d, xp[(int64_t)ff * INNER], acc[i]);
         }
     }
@@ -1470,9 +1588,9 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
                  performer_kv_bf16(st, b.k, b.v, p3, (int)B, (int)Fr, b.cx, b.ks));
             PROF(PF_U2C_GEMM_ATTNOUT, 4.0 * M8 * NF * DH, 4.0 * M * 2 * INNER,
                  performer_q_bf16(st, b.q, p3, b.cx, b.ks, (int)B, (int)Fr, b.attn, 0, asplit));
-        } else if (!b.pre && w.causal) {
-            // causal mode (inference only): feature maps through the GEMM + row kernels of the training path, then the
-            // sequential causal attention kernel
+        } else if (w.causal) {
+            // causal mode: feature maps through the GEMM + row kernels of the training path (q', k' stay in the arena for the
+            // backward pass), then the sequential causal attention kernel
             gemm::Args g = gemm::make(b.q, DH, L.proj, DH, (int)M8, NF, DH);
             gemm::EpiStore e{b.qf, LDF, nullptr, 1, 0, 0};
             PROF(PF_U2C_GEMM_FEAT, 2.0 * M8 * NF * DH, 4.0 * M8 * (DH + NF), (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
@@ -1714,7 +1832,7 @@ static int wgrad_tile_choice() {
 }
 static int layer_grads(ddsp_ctx* ctx, hipStream_t st, const float* dY, int64_t ldy, int O, const float* X, int64_t ldx, int C,
                        int taps, int Fr, int64_t M, float* wpart, float* cpart, float* xs, float* w_out, int64_t ldo,
-                       float* b_out) {
+                       float* b_out, int tap_shift = 0) {   // tap_shift: 0 centred taps, -1 causal taps (taps == 3 only)
     int rc;
     const bool split = ctx->math == DDSP_MATH_SPLIT_BF16 && (taps == 1 || C % 128 == 0);
     if (!split) {
@@ -1722,7 +1840,7 @@ static int layer_grads(ddsp_ctx* ctx, hipStream_t st, const float* dY, int64_t l
             if ((rc = wgrad(ctx, st, dY, ldy, O, X, ldx, C, M, wpart, w_out, ldo, 0))) return rc;
         } else {
             for (int tap = 0; tap < taps; ++tap) {
-                hipLaunchKernelGGL(shift_rows_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, st, X, M, Fr, C, tap - 1, xs);
+                hipLaunchKernelGGL(shift_rows_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, st, X, M, Fr, C, tap - 1 + tap_shift, xs);
                 if ((rc = wgrad(ctx, st, dY, ldy, O, xs, C, C, M, wpart, w_out, ldo, tap * C))) return rc;
             }
         }
@@ -1737,6 +1855,7 @@ static int layer_grads(ddsp_ctx* ctx, hipStream_t st, const float* dY, int64_t l
     g.ldx = ldx;
     g.C = C;
     g.taps = taps;
+    g.tap_shift = taps == 3 ? tap_shift : 0;
     g.Fr = Fr;
     g.M = M;
     g.chunk = wgrad::chunk_for(M, WG_SPLITS);
@@ -1956,12 +2075,13 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
                               GLP(cm_pw2_b)))) return rc;
         dgrad(st, dX, D, L.cm_pw2_w, D, INNER, M, dB512, false, wt_pw2[l]);                                  // d_dwo
         hipLaunchKernelGGL(silu_bwd_kernel, dim3(grid_for(M * INNER)), dim3(256), 0, st, b.pre, dB512, M * INNER, dB512);  // d_pre
-        hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(INNER / 64, (unsigned)B, DWG_CHUNKS), dim3(256), 0, st, dB512, b.glu, (int)Fr, dwpart);
+        hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(INNER / 64, (unsigned)B, DWG_CHUNKS), dim3(256), 0, st, dB512, b.glu, (int)Fr, dwpart,
+                           w.causal ? DWK - 1 : DWK / 2);
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((INNER * DWK + 63) / 64), dim3(256), 0, st, dwpart, (int)B * DWG_CHUNKS,
                            (int64_t)INNER * DWK, GLP(cm_dw_w));
         if ((rc = colsum(ctx, st, dB512, INNER, M, INNER, nullptr, 0, cpart, GLP(cm_dw_b)))) return rc;
         hipLaunchKernelGGL((dwconv_kernel<false, true>), dim3(INNER / 256, (unsigned)(B * ((Fr + DW_RUN - 1) / DW_RUN))),
-                           dim3(256), 0, st, dB512, L.cm_dw_w, nullptr, (int)B, (int)Fr, dC512, nullptr, DWK, 1, DWK / 2, 0);   // d_glu
+                           dim3(256), 0, st, dB512, L.cm_dw_w, nullptr, (int)B, (int)Fr, dC512, nullptr, DWK, 1, w.causal ? 0 : DWK / 2, 0);   // d_glu (adjoint taps: left' = DWK - 1 - left)
         hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for(M * INNER)), dim3(256), 0, st, b.g1, dC512, M, dG1);
         if ((rc = layer_grads(ctx, st, dG1, 2 * INNER, 2 * INNER, b.y2, D, D, 1, (int)Fr, M, wpart, cpart, xs, GLP(cm_pw1_w), D,
                               GLP(cm_pw1_b)))) return rc;
@@ -1974,47 +2094,57 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
         if ((rc = layer_grads(ctx, st, dX, D, D, b.attn, INNER, INNER, 1, (int)Fr, M, wpart, cpart, xs, GLP(out_w), INNER,
                               GLP(out_b)))) return rc;
         dgrad(st, dX, D, L.out_w, D, INNER, M, dB512, false, wt_out[l]);                                       // d_attn
-        hipLaunchKernelGGL(attn_out_bwd_kernel, dim3(rows8_g), dim3(256), 0, st, dB512, b.attn, b.dinv, M8, dD);  // d_num, d_D
-        {   // d_q' = d_num ctx^T + d_D ks^T
-            gemm::Args g = gemm::make(dB512, INNER, b.cx, DH, (int)Fr, NF, DH);
-            g.zdiv = H;
-            g.sA_hi = (int64_t)Fr * INNER;
-            g.sA_lo = DH;
-            g.sB_hi = (int64_t)H * NF * DH;
-            g.sB_lo = (int64_t)NF * DH;
-            EpiRowOuter e{dQF, dD, b.ks, (int)Fr};
-            gemm::launch_tile<64, 64, true, true, gemm::A_PLAIN>(st, g, (int)(B * H), e);
-        }
-        {   // d_ctx = q'^T d_num
-            gemm::Args g = gemm::make(b.qf, (int64_t)H * LDF, dB512, INNER, NF, DH, (int)Fr);
-            g.zdiv = H;
-            g.sA_hi = (int64_t)Fr * H * LDF;
-            g.sA_lo = LDF;
-            g.sB_hi = (int64_t)Fr * INNER;
-            g.sB_lo = DH;
-            gemm::EpiStore e{dcx, DH, nullptr, 1, (int64_t)NF * DH, 0};
-            gemm::launch_tile<64, 64, false, false, gemm::A_PLAIN>(st, g, (int)(B * H), e);
-        }
-        hipLaunchKernelGGL(weighted_key_sum_kernel, dim3((unsigned)(B * H)), dim3(KS_T * 8), 0, st, b.qf, dD, (int)Fr, dks);
-        {   // d_k' = v d_ctx^T + d_ks^T
-            gemm::Args g = gemm::make(b.v, INNER, dcx, DH, (int)Fr, NF, DH);
-            g.zdiv = H;
-            g.sA_hi = (int64_t)Fr * INNER;
-            g.sA_lo = DH;
-            g.sB_hi = (int64_t)H * NF * DH;
-            g.sB_lo = (int64_t)NF * DH;
-            EpiRowOuter e{dKF, nullptr, dks, (int)Fr};
-            gemm::launch_tile<64, 64, true, true, gemm::A_PLAIN>(st, g, (int)(B * H), e);
-        }
-        {   // d_v = k' d_ctx
-            gemm::Args g = gemm::make(b.kf, (int64_t)H * LDF, dcx, DH, (int)Fr, DH, NF);
-            g.zdiv = H;
-            g.sA_hi = (int64_t)Fr * H * LDF;
-            g.sA_lo = LDF;
-            g.sB_hi = (int64_t)H * NF * DH;
-            g.sB_lo = (int64_t)NF * DH;
-            EpiAttnOut e{dV512, nullptr, (int)Fr};
-            gemm::launch_tile<64, 64, true, false, gemm::A_PLAIN>(st, g, (int)(B * H), e);
+        if (w.causal) {
+            // causal attention: three sequential scans per (utterance, head) (dD / coefq hold 1/den and d den between them)
+            hipLaunchKernelGGL(causal_attn_bwd_q_kernel, dim3((unsigned)(B * H)), dim3(320), 0, st, b.qf, b.kf, b.v, dB512, b.attn,
+                               (int)Fr, dQF, dD, coefq);
+            hipLaunchKernelGGL(causal_attn_bwd_k_kernel, dim3((unsigned)(B * H)), dim3(320), 0, st, b.qf, b.v, dB512, dD, coefq,
+                               (int)Fr, dKF);
+            hipLaunchKernelGGL(causal_attn_bwd_v_kernel, dim3((unsigned)(B * H)), dim3(256), 0, st, b.qf, b.kf, dB512, dD, (int)Fr,
+                               dV512);
+        } else {
+            hipLaunchKernelGGL(attn_out_bwd_kernel, dim3(rows8_g), dim3(256), 0, st, dB512, b.attn, b.dinv, M8, dD);  // d_num, d_D
+            {   // d_q' = d_num ctx^T + d_D ks^T
+                gemm::Args g = gemm::make(dB512, INNER, b.cx, DH, (int)Fr, NF, DH);
+                g.zdiv = H;
+                g.sA_hi = (int64_t)Fr * INNER;
+                g.sA_lo = DH;
+                g.sB_hi = (int64_t)H * NF * DH;
+                g.sB_lo = (int64_t)NF * DH;
+                EpiRowOuter e{dQF, dD, b.ks, (int)Fr};
+                gemm::launch_tile<64, 64, true, true, gemm::A_PLAIN>(st, g, (int)(B * H), e);
+            }
+            {   // d_ctx = q'^T d_num
+                gemm::Args g = gemm::make(b.qf, (int64_t)H * LDF, dB512, INNER, NF, DH, (int)Fr);
+                g.zdiv = H;
+                g.sA_hi = (int64_t)Fr * H * LDF;
+                g.sA_lo = LDF;
+                g.sB_hi = (int64_t)Fr * INNER;
+                g.sB_lo = DH;
+                gemm::EpiStore e{dcx, DH, nullptr, 1, (int64_t)NF * DH, 0};
+                gemm::launch_tile<64, 64, false, false, gemm::A_PLAIN>(st, g, (int)(B * H), e);
+            }
+            hipLaunchKernelGGL(weighted_key_sum_kernel, dim3((unsigned)(B * H)), dim3(KS_T * 8), 0, st, b.qf, dD, (int)Fr, dks);
+            {   // d_k' = v d_ctx^T + d_ks^T
+                gemm::Args g = gemm::make(b.v, INNER, dcx, DH, (int)Fr, NF, DH);
+                g.zdiv = H;
+                g.sA_hi = (int64_t)Fr * INNER;
+                g.sA_lo = DH;
+                g.sB_hi = (int64_t)H * NF * DH;
+                g.sB_lo = (int64_t)NF * DH;
+                EpiRowOuter e{dKF, nullptr, dks, (int)Fr};
+                gemm::launch_tile<64, 64, true, true, gemm::A_PLAIN>(st, g, (int)(B * H), e);
+            }
+            {   // d_v = k' d_ctx
+                gemm::Args g = gemm::make(b.kf, (int64_t)H * LDF, dcx, DH, (int)Fr, DH, NF);
+                g.zdiv = H;
+                g.sA_hi = (int64_t)Fr * H * LDF;
+                g.sA_lo = LDF;
+                g.sB_hi = (int64_t)H * NF * DH;
+                g.sB_lo = (int64_t)NF * DH;
+                EpiAttnOut e{dV512, nullptr, (int)Fr};
+                gemm::launch_tile<64, 64, true, false, gemm::A_PLAIN>(st, g, (int)(B * H), e);
+            }
         }
         hipLaunchKernelGGL(feature_map_bwd_kernel<true>, dim3(rows8_g), dim3(256), 0, st, b.qf, dQF, M8, coefq);
         hipLaunchKernelGGL(feature_map_bwd_kernel<false>, dim3(rows8_g), dim3(256), 0, st, b.kf, dKF, M8, coefk);
@@ -2066,13 +2196,15 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
     hipLaunchKernelGGL(spk_table_grad_kernel, dim3((unsigned)w.n_spk), dim3(D), 0, st, dA, B, in.spk_id, in.n_spk_id, in.mix,
                        G(spk_table));
     // ---- prenet conv2: weight gradient over the three taps, input gradient as the flipped conv ----
-    if ((rc = layer_grads(ctx, st, dX, D, D, bf.t2, D, D, 3, (int)Fr, M, wpart, cpart, xs, pk, 3 * D, G(prenet_conv2_b)))) return rc;
+    if ((rc = layer_grads(ctx, st, dX, D, D, bf.t2, D, D, 3, (int)Fr, M, wpart, cpart, xs, pk, 3 * D, G(prenet_conv2_b),
+                          w.causal ? -1 : 0))) return rc;
     hipLaunchKernelGGL(unpack_conv3_kernel, dim3(grid_for((int64_t)D * D * 3)), dim3(256), 0, st, pk, D, D, G(prenet_conv2_w));
     hipLaunchKernelGGL(pack_conv3_transposed_kernel, dim3(grid_for((int64_t)D * D * 3)), dim3(256), 0, st, w.prenet_conv2_w, D, D, w2t);
     {
         gemm::Args g = gemm::make(dX, D, w2t, 3 * D, (int)M, D, 3 * D);
         g.Fr = (int)Fr;
         g.Cin = D;
+        g.tap_shift = w.causal ? 1 : 0;   // the adjoint of taps (-2, -1, 0) reads frames (0, +1, +2) of dX
         if (int rc = ddsp_zero_page(ctx, &g.zeros)) return rc;
         gemm::EpiStore e{dA, D, nullptr, 1, 0, 0};
         gemm::launch<true, true, gemm::A_CONV3>(st, g, 1, e);                                      // d_t2
@@ -2085,7 +2217,7 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
     if ((rc = colsum_pair(ctx, st, gx, dA, D, M, D, cpart, G(prenet_gn_w), G(prenet_gn_b)))) return rc;
     // ---- prenet conv1 (the units carry no gradient) ----
     if ((rc = layer_grads(ctx, st, dX, D, D, in.units, w.n_unit, w.n_unit, 3, (int)Fr, M, wpart, cpart, xs, pk, 3 * w.n_unit,
-                          G(prenet_conv1_b)))) return rc;
+                          G(prenet_conv1_b), w.causal ? -1 : 0))) return rc;
     hipLaunchKernelGGL(unpack_conv3_kernel, dim3(grid_for((int64_t)D * w.n_unit * 3)), dim3(256), 0, st, pk, D, w.n_unit,
                        G(prenet_conv1_w));
     DDSP_LAUNCH_CHECK(ctx);
@@ -2103,7 +2235,6 @@ extern "C" int ddsp_unit2ctrl_bwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
                           n_mix, B, Fr, in);
     if (rc) return rc;
     DDSP_REQUIRE(ctx, d_ctrl && grads_host, "ddsp_unit2ctrl_bwd: null argument");
-    DDSP_REQUIRE(ctx, !wp->causal, "ddsp_unit2ctrl_bwd: the causal network (c: true) is built for inference only");
     if ((rc = ddsp_take_dev_error(ctx))) return rc;
     if (B == 0) return DDSP_OK;
     DDSP_ENTER_DEVICE(ctx);
@@ -2129,7 +2260,6 @@ extern "C" int ddsp_unit2ctrl_fwd_keep(ddsp_ctx* ctx, void* stream, const ddsp_u
                           n_mix, B, Fr, in);
     if (rc) return rc;
     DDSP_REQUIRE(ctx, ctrl && keep && ((uintptr_t)keep % 256) == 0, "ddsp_unit2ctrl_fwd_keep: null ctrl / keep, or keep not 256-byte aligned");
-    DDSP_REQUIRE(ctx, !wp->causal, "ddsp_unit2ctrl_fwd_keep: the causal network (c: true) is built for inference only");
     if ((rc = ddsp_take_dev_error(ctx))) return rc;
     if (B == 0) return DDSP_OK;
     DDSP_ENTER_DEVICE(ctx);
@@ -2150,7 +2280,6 @@ extern "C" int ddsp_unit2ctrl_bwd_kept(ddsp_ctx* ctx, void* stream, const ddsp_u
                           n_mix, B, Fr, in);
     if (rc) return rc;
     DDSP_REQUIRE(ctx, d_ctrl && grads_host && keep && ((uintptr_t)keep % 256) == 0, "ddsp_unit2ctrl_bwd_kept: null argument or keep not 256-byte aligned");
-    DDSP_REQUIRE(ctx, !wp->causal, "ddsp_unit2ctrl_bwd_kept: the causal network (c: true) is built for inference only");
     if ((rc = ddsp_take_dev_error(ctx))) return rc;
     if (B == 0) return DDSP_OK;
     DDSP_ENTER_DEVICE(ctx);

@@ -1,6 +1,6 @@
 // Weight gradients of the Linear / Conv1d(k=3) layers on the bf16 matrix pipe (split-bf16, 3 products, fp32 accumulation).
 //
-//   out[o][t*C + c] = sum_m dY[m][o] * X[m + t - (taps-1)/2][c]      (rows outside the utterance of m contribute 0)
+//   out[o][t*C + c] = sum_m dY[m][o] * X[m + t - (taps-1)/2 + tap_shift][c]   (rows outside the utterance of m contribute 0)
 //   bias[o]         = sum_m dY[m][o]                                 (optional)
 //
 // Both operands are stored with the CONTRACTION index m as the slow one (frames x channels), the opposite of what the
@@ -28,7 +28,8 @@ struct Args {
     const float* X;
     int64_t ldx;
     int C;       // channels per tap
-    int taps;    // 1 (Linear) or 3 (Conv1d k=3, centred): column block t reads X shifted by t - 1 frames
+    int taps;    // 1 (Linear) or 3 (Conv1d k=3): column block t reads X shifted by t - 1 + tap_shift frames
+    int tap_shift;   // 0: centred taps, -1: causal taps (frames -2, -1, 0)
     int Fr;      // frames per utterance (the shift does not cross utterances)
     int64_t M;   // rows = utterances x frames
     int chunk;   // rows per split, a multiple of 32
@@ -49,7 +50,7 @@ __global__ void __launch_bounds__(256) kernel(Args g) {
     const int o0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int N = g.taps * g.C;
     const int tap = n0 / g.C, c0 = n0 - tap * g.C;
-    const int shift = tap - (g.taps - 1) / 2;
+    const int shift = tap - (g.taps - 1) / 2 + g.tap_shift;
     const int z = blockIdx.z;
     const int64_t kbeg = (int64_t)z * g.chunk;
     const int64_t kend = kbeg + g.chunk < g.M ? kbeg + g.chunk : g.M;

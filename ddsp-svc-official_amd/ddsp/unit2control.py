@@ -131,7 +131,7 @@ def split_to_dict(tensor, tensor_splits):
 class Unit2Control(nn.Module):
     def __init__(self, ndim_feat_i, n_spk, output_splits, c=False):
         super().__init__()
-        # c = True: causal convolutions (taps at frames t-k+1 .. t) and causal linear attention, inference only.  The two
+        # c = True: causal convolutions (taps at frames t-k+1 .. t) and causal linear attention, forward and backward.  The two
         # third-party primitives behind it (extorch.Conv1dEx(causal=True), fast_transformers.CausalDotProduct) are not in
         # the image: they are restated from their definitions, parity at that boundary is unpinned.
         self.causal = bool(c)
@@ -184,8 +184,6 @@ class Unit2Control(nn.Module):
         `ctx`: the context of the forward call (autograd runs backward on its own thread; reusing the forward's
         context keeps one scratch arena and one profiler per model call).  `kept`: the activation region of a
         `forward_flat_keep` call on the same inputs and weights - without it the forward is re-run inside the call."""
-        if self.causal:
-            raise NotImplementedError("the causal network (c: true) is built for inference only")
         ctx = ctx or hipddsp.context_for(units.device)
         w, keep = self._weights_struct()
         g = hipddsp.U2CWeights()
@@ -259,8 +257,6 @@ class Unit2Control(nn.Module):
         """Training forward: (control matrix, kept activations) - PyTorch keeps a module's activations for `backward`
         (reference `solver.py:111-113`); here the library leaves them in one device region that `backward_flat(kept=...)`
         starts from, so the network runs once per step."""
-        if self.causal:
-            raise NotImplementedError("the causal network (c: true) is built for inference only")
         ctx = ctx or hipddsp.context_for(units.device)
         w, keep = self._weights_struct()
         return ctx.unit2ctrl_keep(w, units, f0, phase, volume, spk_id, spk_mix_dict, self.n_out)

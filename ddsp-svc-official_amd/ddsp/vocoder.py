@@ -7,8 +7,8 @@ Differences a caller can observe, all additive:
     mt19937 stream (`torch.rand_like`), which a GPU cannot reproduce.  `noise` (B,T) U[0,1) injects the
     draw (parity runs); otherwise a counter-based in-kernel generator is used, seeded from torch's default
     generator (so `torch.manual_seed` still makes a run repeatable) or from `noise_seed`.
-  * `c=True` (causal convolutions + causal linear attention) is built for inference; training it raises
-    NotImplementedError.
+  * `c=True` (causal convolutions + causal linear attention): forward and training; the two third-party primitives
+    behind it are restated from their definitions.
 """
 import os
 

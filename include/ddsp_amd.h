@@ -129,7 +129,7 @@ typedef struct ddsp_u2c_weights {
     const float *prenet_conv1_w, *prenet_conv1_b, *prenet_gn_w, *prenet_gn_b, *prenet_conv2_w, *prenet_conv2_b;
     const float *f0_w, *f0_b, *phase_w, *phase_b, *volume_w, *volume_b, *spk_table;
     int n_spk, n_unit, n_out;
-    int causal;   /* 0 = the shipped configs (`c: false`); 1 = causal convolutions + causal linear attention, inference only */
+    int causal;   /* 0 = the shipped configs (`c: false`); 1 = causal convolutions + causal linear attention */
     ddsp_u2c_layer layer[3];
     const float *final_ln_w, *final_ln_b, *head_g, *head_v, *head_b;
 } ddsp_u2c_weights;

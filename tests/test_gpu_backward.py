@@ -86,11 +86,21 @@ def test_fir_from_ctrl_adjoint(ctx, dev, mode, n_mag):
 # ---- control network backward -------------------------------------------------------------------------
 # (24, 172): 4128 rows - from 4033 rows on the prenet convs (forward recompute AND the d_t2 adjoint) run the LDS-DMA
 # implicit-im2col GEMM instead of the register-staged one, and the N <= 256 layers the 4-wave 64x64 tile
-@pytest.mark.parametrize("B,Fr,spk_mode", [(2, 12, "per_row"), (3, 40, "broadcast"), (2, 172, "mix"), (24, 172, "per_row")])
-def test_unit2ctrl_parameter_gradients(dev, lib_path, B, Fr, spk_mode):
+# causal = True: the `c: true` network (causal taps in the three convolutions, causal linear attention): its backward is three
+# sequential scans per (utterance, head) and shifted taps in the conv adjoints; the oracle restates the two third-party causal
+# primitives from their definitions (oracle/ctrlnet.py), autograd differentiates that restatement
+@pytest.mark.parametrize("B,Fr,spk_mode,causal", [(2, 12, "per_row", False), (3, 40, "broadcast", False), (2, 172, "mix", False),
+                                                  (24, 172, "per_row", False), (2, 12, "per_row", True), (3, 47, "mix", True),
+                                                  (24, 172, "broadcast", True)])
+def test_unit2ctrl_parameter_gradients(dev, lib_path, B, Fr, spk_mode, causal):
     import synthetic
     from oracle import ctrlnet as OC
     model, cfg = synthetic.build_model("CombSub", seed=31)
+    if causal:
+        from ddsp.vocoder import CombSub
+        cm = CombSub(44100, 512, cfg["n_mag_allpass"], cfg["n_mag_harmonic"], cfg["n_mag_noise"], cfg["n_unit"], cfg["n_spk"], c=True)
+        cm.load_state_dict(model.state_dict(), strict=True)
+        model = cm
     u2c = model.unit2ctrl
     inp = synthetic.make_inputs(100 + Fr, B, Fr, with_noise=False)
     r = _rng(Fr)
@@ -103,7 +113,8 @@ def test_unit2ctrl_parameter_gradients(dev, lib_path, B, Fr, spk_mode):
     # oracle gradients by autograd
     sd = {k: v.clone().requires_grad_(v.is_floating_point() and "projection_matrix" not in k)
           for k, v in u2c.state_dict().items()}
-    out = OC.unit2control(sd, inp["units"], inp["f0"], phase, inp["volume"], spk, mix, u2c.output_splits, return_flat=True)
+    out = OC.unit2control(sd, inp["units"], inp["f0"], phase, inp["volume"], spk, mix, u2c.output_splits, return_flat=True,
+                          causal=causal)
     (out * d_ctrl).sum().backward()
     model = model.to(dev)
     grads = model.unit2ctrl.backward_flat(inp["units"].to(dev), inp["f0"].to(dev), phase.to(dev), inp["volume"].to(dev),

@@ -487,11 +487,25 @@ def test_causal_mode_against_reference_fixture(dev, lib_path):
         with torch.no_grad():
             sig = model(d["units"], d["f0"], d["volume"], d["spk_id"], noise=d["noise"])[0]
         assert rms(sig[pick].cpu() - sig_o) < GATE, (B, Fr, rms(sig[pick].cpu() - sig_o))
-    # training the causal network is not built: it must say so, not silently train the non-causal one
+    # training: the whole model's gradients against autograd through the oracle (exact-phase mode, like the non-causal test
+    # of tests/test_gpu_training.py; the network's own backward is checked parameter by parameter in test_gpu_backward.py)
     model.train()
-    with pytest.raises((NotImplementedError, ValueError)):
-        out = model(d["units"][:1, :8], d["f0"][:1, :8], d["volume"][:1, :8], d["spk_id"][:1], infer=False, noise=d["noise"][:1, :4096])[0]
-        out.sum().backward()
+    inp = synthetic.make_inputs(71, 2, 40)
+    d = _to(inp, dev)
+    sig = model(d["units"], d["f0"], d["volume"], d["spk_id"], infer=True, noise=d["noise"])[0]
+    gsig = torch.from_numpy(np.random.default_rng(5).standard_normal(tuple(sig.shape)).astype(np.float32)) / sig.numel()
+    (sig * gsig.to(dev)).sum().backward()
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "projection_matrix" not in k and v.dim() > 0)
+          for k, v in ref_model.state_dict().items()}
+    sig_o = OS.combsub_forward(sd, ccfg, inp["units"], inp["f0"], inp["volume"], inp["spk_id"], noise=inp["noise"])[0]
+    assert rms(sig.detach().cpu() - sig_o.detach()) < GATE
+    (sig_o * gsig).sum().backward()
+    errs = []
+    for n, p in model.named_parameters():
+        want = sd[n].grad
+        errs.append((float((p.grad.cpu().double() - want.double()).norm() / (want.double().norm() + 1e-30)), n))
+    errs.sort(reverse=True)
+    assert errs[0][0] < 5e-3 and sum(e for e, _ in errs) / len(errs) < 1e-3, errs[:5]
 
 
 def test_stream_switch_under_a_cached_context(dev, lib_path):
