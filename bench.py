@@ -295,7 +295,8 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": ("f32 storage and accumulation; products of the GEMM/FIR contractions split-bf16x3 (hi*hi+hi*lo+lo*hi), "
                   "attention and all other arithmetic f32; `value_fp32_mfma` is the all-f32 leg") if args.mode == "synth"
-        else "f32 (forward GEMM/FIR products split-bf16x3; backward, loss and optimizer f32)",
+        else "f32 storage and accumulation; forward, spectral loss, attention / FIR adjoints and optimizer in f32 products; "
+             "weight and input gradients of the Linear / conv layers split-bf16x3 (hi*hi+hi*lo+lo*hi)",
         "data": "synthetic",
         "config": {"workload": f"{args.model} 44.1 kHz, batch={Bt}x2 s per GPU (Fr={FRAMES}, T={T}), "
                                + ("units/f0/volume/spk_id -> audio, seeded random weights, in-kernel noise"
