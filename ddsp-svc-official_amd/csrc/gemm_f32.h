@@ -9,8 +9,9 @@
 //                 (m % Fr) + tap - 1 stays inside [0, Fr), else 0: a zero-padded k=3 Conv1d over the
 //                 frame axis without materialising im2col.
 //   A_MODE = A_CONVK: the same with `ktaps` taps `dil` frames apart, centred ("same" padding: tap t reads frame
-//                 m + (t - (ktaps-1)/2)*dil), and an optional leaky-ReLU (slope `in_slope`) applied to A as it is loaded: the
-//                 dilated convolutions of the NSF-HiFiGAN generator (register-staged kernel only).
+//                 m + (t - (ktaps-1)/2)*dil): the dilated convolutions of the NSF-HiFiGAN generator.  The register-staged
+//                 kernel can apply a leaky-ReLU (slope `in_slope`) to A as it is loaded; the LDS-DMA kernel (Cin % 32 == 0,
+//                 in_slope == 1, `zeros` set) cannot - its callers feed it activated inputs.
 //   A_MODE = A_FRAMES: rows are non-overlapping length-lda frames of B signals: row m lives at
 //                 A[(m / Fr)*sA_hi + (m % Fr)*lda] (Fr frames per signal, signals sA_hi apart) - the STFT framing of
 //                 the spectral loss without a copy.
@@ -416,6 +417,7 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ?
     static_assert((BM / 8) % NW == 0, "A rows must split evenly over the waves");
     const float* src_m1[PA];                 // taps 0 and 2 (tap 1 lives in src[])
     const float* src_p1[PA];
+    int conv_f[PA];                          // A_CONVK: frame (inside its utterance) of each A row this wave fetches
     auto tile_src = [&](int tile, const float* (&src)[PPW]) {
         const int per_z = tiles_m * tiles_n;
         int z = tile / per_z, rem = tile - z * per_z;
@@ -437,6 +439,11 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ?
                 int m = m0 + row;
                 m = m < g.M ? m : g.M - 1;
                 src[i] = A + (int64_t)m * g.lda + slot * 4;
+                if constexpr (A_MODE == A_CONVK) {
+                    // (k = tap*Cin + c; the tap of a k-step is wave-uniform because Cin % 32 == 0: issue() moves the row
+                    // pointer by the tap's frame offset, or to the zero page when that frame is outside the utterance)
+                    if (i < PA) conv_f[i < PA ? i : 0] = m % g.Fr;
+                }
                 if constexpr (A_MODE == A_CONV3) {
                     if (i < PA) {
                         const int f = m % g.Fr;
@@ -458,16 +465,23 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ?
     };
     auto issue = [&](const float* const (&src)[PPW], int kt, int stage) {
         int tap = 1, koff = kt * 32;
-        if constexpr (A_MODE == A_CONV3) {
+        if constexpr (A_MODE == A_CONV3 || A_MODE == A_CONVK) {
             tap = koff / g.Cin;
             koff -= tap * g.Cin;
         }
+        const int conv_off = A_MODE == A_CONVK ? (tap - (g.ktaps - 1) / 2) * g.dil : 0;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int piece = wave + NW * i;
             const float* p = src[i] + kt * 32;
             if constexpr (A_MODE == A_CONV3) {
                 if (i < PA) p = (tap == 0 ? src_m1[i < PA ? i : 0] : tap == 1 ? src[i] : src_p1[i < PA ? i : 0]) + koff;
+            }
+            if constexpr (A_MODE == A_CONVK) {
+                if (i < PA) {
+                    const int f = conv_f[i < PA ? i : 0] + conv_off;
+                    p = (f >= 0 && f < g.Fr) ? src[i] + (int64_t)conv_off * g.lda + koff : g.zeros + (lane & 7) * 4;
+                }
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                              (__attribute__((address_space(3))) void*)(lds + stage * STAGE + piece * 256),

@@ -97,12 +97,14 @@ __global__ void __launch_bounds__(256) nsf_post_kernel(const float* __restrict__
 
 __global__ void __launch_bounds__(256) nsf_mean_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                        const float* __restrict__ c, int n_terms, int64_t n,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, float* __restrict__ out_act, float slope) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float s = a[i];
         if (n_terms > 1) s += b[i];
         if (n_terms > 2) s += c[i];
-        out[i] = s / (float)n_terms;
+        s = s / (float)n_terms;
+        if (out) out[i] = s;
+        if (out_act) out_act[i] = s > 0.f ? s : s * slope;
     }
 }
 
@@ -125,28 +127,49 @@ __global__ void __launch_bounds__(256) nsf_logclamp_kernel(float* __restrict__ x
     if (i < n) x[i] = logf(fmaxf(x[i], clip));
 }
 
-struct EpiAddBias {   // C = acc + bias[n] (+ res): the plain and the residual / source-addition epilogue of the generator's convs
+struct EpiAddBias {   // y = acc + bias[n] (+ res): C = y and / or Cact = leaky_relu(y, slope) - the consumer convolutions of the
+                      // generator all read an activated input, the residual paths the raw one
     float* C;
+    float* Cact;
     const float* res;
     int64_t ldc;
     const float* bias;
+    float slope;
     __device__ __forceinline__ float col(int n) const { return bias ? bias[n] : 0.f; }
     __device__ __forceinline__ void operator()(int, int m, int n, float v, float cb) const {
         const int64_t o = (int64_t)m * ldc + n;
-        const float y = v + cb;
-        C[o] = res ? y + res[o] : y;
+        float y = v + cb;
+        if (res) y += res[o];
+        if (C) C[o] = y;
+        if (Cact) Cact[o] = y > 0.f ? y : y * slope;
+    }
+    static constexpr bool kStore4 = true;
+    __device__ __forceinline__ bool vec_ok() const {
+        return (((uintptr_t)C | (uintptr_t)Cact | (uintptr_t)res) % 16) == 0 && ldc % 4 == 0;
+    }
+    __device__ __forceinline__ void store4(int, int m, int n, f32x4 v) const {
+        const int64_t o = (int64_t)m * ldc + n;
+        if (bias) v += *(const gemm::f32x4_u*)(bias + n);
+        if (res) v += *(const f32x4*)(res + o);
+        if (C) *(f32x4*)(C + o) = v;
+        if (Cact) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
+            *(f32x4*)(Cact + o) = v;
+        }
     }
 };
 
 }  // namespace
 
 extern "C" int ddsp_conv1d(ddsp_ctx* ctx, void* stream, const float* x, const float* w_packed, const float* bias, int64_t T,
-                           int Cin, int Cout, int ktaps, int dil, float in_slope, const float* residual, float* out) {
-    DDSP_REQUIRE(ctx, ctx && x && w_packed && out, "ddsp_conv1d: null argument");
+                           int Cin, int Cout, int ktaps, int dil, float in_slope, const float* residual, float* out,
+                           float* out_act, float act_slope) {
+    DDSP_REQUIRE(ctx, ctx && x && w_packed && (out || out_act), "ddsp_conv1d: null argument");
     DDSP_REQUIRE(ctx, T >= 1 && T < (1 << 30) && Cin >= 4 && Cin % 4 == 0 && Cout >= 1 && ktaps >= 1 && ktaps % 2 == 1 &&
                           ktaps <= 63 && dil >= 1 && dil <= 64,
                  "ddsp_conv1d: bad shape (Cin % 4 == 0, odd tap count)");
-    DDSP_REQUIRE(ctx, x != out, "ddsp_conv1d: in-place convolution is not possible");
+    DDSP_REQUIRE(ctx, x != out && x != out_act, "ddsp_conv1d: in-place convolution is not possible");
     hipStream_t st = (hipStream_t)stream;
     DDSP_ENTER_DEVICE(ctx);
     gemm::Args g = gemm::make(x, Cin, w_packed, (int64_t)ktaps * Cin, (int)T, Cout, ktaps * Cin);
@@ -155,9 +178,19 @@ extern "C" int ddsp_conv1d(ddsp_ctx* ctx, void* stream, const float* x, const fl
     g.ktaps = ktaps;
     g.dil = dil;
     g.in_slope = in_slope;
-    EpiAddBias e{out, residual, Cout, bias};
+    EpiAddBias e{out, out_act, residual, Cout, bias, act_slope};
+    auto blocks = [&](int bm, int bn) { return (int64_t)((T + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
     ddsp_prof_begin(ctx, st, PF_OTHER);
-    if ((int64_t)((T + 127) / 128) * ((Cout + 63) / 64) >= 512)
+    if (in_slope == 1.0f && Cin % 32 == 0 && gemm::dma_ok(g)) {
+        // an input that needs no activation on load: the LDS-DMA kernel with per-tap row pointers, products in the context's
+        // arithmetic (split-bf16 by default, ddsp_ctx_set_math(FP32) for fp32 products)
+        if (int rc = ddsp_zero_page(ctx, &g.zeros)) return rc;
+        g.math = ctx->math == DDSP_MATH_FP32 ? 0 : DDSP_MATH_SPLIT_BF16;
+        if (Cout > 256 && blocks(128, 128) >= 512)
+            gemm::dma_go<128, 128, EpiAddBias, 2, 8, gemm::A_CONVK>(st, g, 1, e);
+        else
+            gemm::dma_go<64, 64, EpiAddBias, 3, 4, gemm::A_CONVK>(st, g, 1, e);
+    } else if (blocks(128, 64) >= 512)
         gemm::launch_tile<128, 64, true, true, gemm::A_CONVK, EpiAddBias, 8>(st, g, 1, e);
     else
         gemm::launch_tile<64, 64, true, true, gemm::A_CONVK, EpiAddBias, 4>(st, g, 1, e);
@@ -211,15 +244,15 @@ extern "C" int ddsp_nsf_post(ddsp_ctx* ctx, void* stream, const float* x, const 
 }
 
 extern "C" int ddsp_nsf_mean(ddsp_ctx* ctx, void* stream, const float* a, const float* b, const float* c, int n_terms, int64_t n,
-                             float* out) {
-    DDSP_REQUIRE(ctx, ctx && a && out && n_terms >= 1 && n_terms <= 3 && (n_terms < 2 || b) && (n_terms < 3 || c) && n >= 0,
+                             float* out, float* out_act, float act_slope) {
+    DDSP_REQUIRE(ctx, ctx && a && (out || out_act) && n_terms >= 1 && n_terms <= 3 && (n_terms < 2 || b) && (n_terms < 3 || c) && n >= 0,
                  "ddsp_nsf_mean: bad argument");
     if (n == 0) return DDSP_OK;
     hipStream_t st = (hipStream_t)stream;
     DDSP_ENTER_DEVICE(ctx);
     int64_t blocks = (n + 255) / 256;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(nsf_mean_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, b, c, n_terms, n, out);
+    hipLaunchKernelGGL(nsf_mean_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, b, c, n_terms, n, out, out_act, act_slope);
     DDSP_LAUNCH_CHECK(ctx);
     return DDSP_OK;
 }

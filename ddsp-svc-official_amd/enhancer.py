@@ -241,24 +241,35 @@ class Generator(torch.nn.Module):
         rand_ini = rand_ini.clone().float().reshape(9)
         rand_ini[0] = 0
         src = c.nsf_source(f0, rand_ini.to(x.device), P["lin_w"], P["lin_b"], self.upp, int(self.h.sampling_rate), 0.1)
-        cur = c.conv1d(x[0].t().contiguous(), P["pre_w"], P["pre_b"], P["pre_k"], 1, 1.0)          # (L, C0)
+        # Every convolution below reads leaky_relu(., 0.1) of its producer's result (models.py:60-62, 251): the producers
+        # write that activated copy themselves (`act_slope`), next to the raw result where a residual path or the stage mean
+        # needs it, so that the consumers take their input as it is (in_slope = 1) and run on the LDS-DMA GEMM.
+        _, cur_act = c.conv1d(x[0].t().contiguous(), P["pre_w"], P["pre_b"], P["pre_k"], 1, 1.0, want_out=False,
+                              act_slope=LRELU_SLOPE)                                               # (L, C0)
         T = L
+        cur = None
         for i in range(self.num_upsamples):
             w_up, b_up, u, cout = P["ups"][i]
             nw, nb, (nk, ns, npad) = P["noise"][i]
             T_out = T * u
             x_source = c.nsf_noise_conv(src, nw, nb, nk, ns, npad, T_out)                          # (T_out, cout)
-            up = c.conv1d(cur, w_up, b_up, 3, 1, LRELU_SLOPE, residual=x_source.reshape(T, u * cout))
-            cur = up.reshape(T_out, cout)
+            up, up_act = c.conv1d(cur_act, w_up, b_up, 3, 1, 1.0, residual=x_source.reshape(T, u * cout), act_slope=LRELU_SLOPE)
+            cur, cur_act = up.reshape(T_out, cout), up_act.reshape(T_out, cout)
             T = T_out
             outs = []
             for convs in P["res"][i]:
-                xr = cur
-                for (w1, b1, d, w2, b2, k) in convs:
-                    xt = c.conv1d(xr, w1, b1, k, d, LRELU_SLOPE)
-                    xr = c.conv1d(xt, w2, b2, k, 1, LRELU_SLOPE, residual=xr)
+                xr, xr_act = cur, cur_act
+                for t, (w1, b1, d, w2, b2, k) in enumerate(convs):
+                    _, xt_act = c.conv1d(xr_act, w1, b1, k, d, 1.0, want_out=False, act_slope=LRELU_SLOPE)
+                    if t + 1 < len(convs):
+                        xr, xr_act = c.conv1d(xt_act, w2, b2, k, 1, 1.0, residual=xr, act_slope=LRELU_SLOPE)
+                    else:
+                        xr = c.conv1d(xt_act, w2, b2, k, 1, 1.0, residual=xr)
                 outs.append(xr)
-            cur = c.nsf_mean(outs)
+            if i + 1 < self.num_upsamples:
+                _, cur_act = c.nsf_mean(outs, want_out=False, act_slope=LRELU_SLOPE)
+            else:
+                cur = c.nsf_mean(outs)
         audio = c.nsf_post(cur, P["post_w"], P["post_b"], P["post_k"], 0.01)
         return audio.reshape(1, 1, -1)
 

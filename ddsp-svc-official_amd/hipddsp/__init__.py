@@ -76,11 +76,11 @@ SIGNATURES = {
     "ddsp_align_units": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp]),
     "ddsp_resample_length": (_i64, [_i64, _int, _int]),
     "ddsp_resample": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _int, _vp]),
-    "ddsp_conv1d": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _vp, _vp]),
+    "ddsp_conv1d": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _vp, _vp, _vp, _f32]),
     "ddsp_nsf_source": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _f32, _vp]),
     "ddsp_nsf_noise_conv": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _int, _int, _int, _int, _i64, _vp]),
     "ddsp_nsf_post": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _f32, _vp]),
-    "ddsp_nsf_mean": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]),
+    "ddsp_nsf_mean": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _i64, _vp, _vp, _f32]),
     "ddsp_log_mel": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _f32, _vp]),
     "ddsp_adamw_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64]),
     "ddsp_adamw_step_multi": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _i64]),
@@ -421,16 +421,20 @@ class Context:
         return out[0] if flat else out
 
     # -- NSF-HiFiGAN post-net building blocks --------------------------------
-    def conv1d(self, x, w_packed, bias, ktaps, dil, in_slope, residual=None):
-        """x (T,Cin), w_packed (Cout, ktaps*Cin) -> (T,Cout) = conv_same(leaky_relu(x, in_slope)) + bias (+ residual)."""
+    def conv1d(self, x, w_packed, bias, ktaps, dil, in_slope, residual=None, want_out=True, act_slope=None):
+        """x (T,Cin), w_packed (Cout, ktaps*Cin) -> y (T,Cout) = conv_same(leaky_relu(x, in_slope)) + bias (+ residual).
+        Returns y, or (y | None, leaky_relu(y, act_slope)) when act_slope is given (want_out=False skips y itself)."""
         T, Cin = x.shape
         Cout = w_packed.shape[0]
         if w_packed.shape[1] != ktaps * Cin:
             raise ValueError("conv1d: packed weight does not match (ktaps, Cin)")
-        out = torch.empty(T, Cout, device=x.device, dtype=torch.float32)
+        out = torch.empty(T, Cout, device=x.device, dtype=torch.float32) if want_out else None
+        act = torch.empty(T, Cout, device=x.device, dtype=torch.float32) if act_slope is not None else None
+        if out is None and act is None:
+            raise ValueError("conv1d: nothing to return")
         self.call("ddsp_conv1d", _ptr(x), _ptr(w_packed), _ptr(bias), T, Cin, Cout, int(ktaps), int(dil), float(in_slope),
-                  _ptr(residual), _ptr(out))
-        return out
+                  _ptr(residual), _ptr(out), _ptr(act), float(act_slope if act_slope is not None else 1.0))
+        return out if act_slope is None else (out, act)
 
     def nsf_source(self, f0, rand_ini, lin_w, lin_b, upp, sr, sine_amp=0.1):
         L = f0.numel()
@@ -452,13 +456,16 @@ class Context:
         self.call("ddsp_nsf_post", _ptr(x), _ptr(w), _ptr(b), T, C, int(K), float(slope), _ptr(out))
         return out
 
-    def nsf_mean(self, terms):
+    def nsf_mean(self, terms, want_out=True, act_slope=None):
+        """Mean of up to three tensors -> out, or (out | None, leaky_relu(out, act_slope)) when act_slope is given."""
         a = terms[0]
-        out = torch.empty_like(a)
+        out = torch.empty_like(a) if want_out else None
+        act = torch.empty_like(a) if act_slope is not None else None
         b = terms[1] if len(terms) > 1 else None
         c = terms[2] if len(terms) > 2 else None
-        self.call("ddsp_nsf_mean", _ptr(a), _ptr(b), _ptr(c), len(terms), a.numel(), _ptr(out))
-        return out
+        self.call("ddsp_nsf_mean", _ptr(a), _ptr(b), _ptr(c), len(terms), a.numel(), _ptr(out), _ptr(act),
+                  float(act_slope if act_slope is not None else 1.0))
+        return out if act_slope is None else (out, act)
 
     def log_mel(self, frames, dft_table, mel_basis, clip):
         n_frames, n_fft = frames.shape

@@ -270,19 +270,25 @@ int ddsp_resample(ddsp_ctx* ctx, void* stream, const float* x, int64_t B, int64_
  * ddsp_conv1d: replaces `Conv1d(Cin, Cout, k, dilation=d, padding="same")(leaky_relu(x, in_slope))` (+ residual): the
  *   resblock convolutions (models.py:45-77), conv_pre (:234) and - with weights packed as the host mirror's
  *   `_pack_conv_transpose` does - the ConvTranspose1d upsamplers (:240-243).  x (T,Cin), w_packed (Cout, k*Cin) with column
- *   tap*Cin + ci, bias (Cout) or NULL, residual (T,Cout) or NULL, out (T,Cout); in_slope = 1 applies no activation.
+ *   tap*Cin + ci, bias (Cout) or NULL, residual (T,Cout) or NULL; in_slope = 1 applies no activation.  The result y goes to
+ *   out (T,Cout) and / or, as leaky_relu(y, act_slope), to out_act (either may be NULL): every convolution of the generator
+ *   reads an activated input, so a producer that emits it lets the consumer run with in_slope = 1 - and only then (with
+ *   Cin % 32 == 0) does the convolution run on the LDS-DMA GEMM in the context's product arithmetic; otherwise on the
+ *   register-staged fp32 kernel, which activates while loading.
  * ddsp_nsf_source: replaces `SourceModuleHnNSF.forward(f0, upp)` (:180-216 with `SineGen` :106-177, 9 harmonics): f0 (L) Hz per
  *   frame, rand_ini (9) the harmonics' initial phases in cycles (the reference's torch.rand draw, element 0 = 0), lin_w (9),
  *   lin_b (1) of `l_linear`; out (L*upp) = tanh(linear(sine_amp * sin(2 pi cumsum(f0 h / sr)))).
  * ddsp_nsf_noise_conv: replaces `noise_convs[i]` (:244-249), a Conv1d(1, C, K, stride, padding=pad) on the source signal:
  *   src (T_src), w (C,K), b (C) -> out (T_out, C).
  * ddsp_nsf_post: replaces `tanh(conv_post(leaky_relu(x, slope)))` (:268-270): x (T,C), w (K,C) tap-major, b (1) -> out (T).
- * ddsp_nsf_mean: (a [+ b [+ c]]) / n_terms elementwise - the mean over a stage's residual blocks (:259-266).
+ * ddsp_nsf_mean: (a [+ b [+ c]]) / n_terms elementwise - the mean over a stage's residual blocks (:259-266) - to out and / or,
+ *   activated, to out_act (as in ddsp_conv1d).
  * ddsp_log_mel: replaces the spectral half of `STFT.get_mel` (nvSTFT.py:100-117): frames (n_frames, n_fft) of the padded
  *   signal, dft_table (2*ldm, n_fft) rows (w cos, -w sin) per bin with ldm = bins rounded up to 4, mel_basis (n_mels, ldm);
  *   out (n_frames, n_mels) = log(max(mel . sqrt(re^2 + im^2 + 1e-9), clip)). */
 int ddsp_conv1d(ddsp_ctx* ctx, void* stream, const float* x, const float* w_packed, const float* bias, int64_t T, int Cin,
-                int Cout, int ktaps, int dil, float in_slope, const float* residual, float* out);
+                int Cout, int ktaps, int dil, float in_slope, const float* residual, float* out, float* out_act,
+                float act_slope);
 int ddsp_nsf_source(ddsp_ctx* ctx, void* stream, const float* f0, const float* rand_ini, const float* lin_w,
                     const float* lin_b, int64_t L, int upp, int sr, float sine_amp, float* out);
 int ddsp_nsf_noise_conv(ddsp_ctx* ctx, void* stream, const float* src, int64_t T_src, const float* w, const float* b, int C,
@@ -290,7 +296,7 @@ int ddsp_nsf_noise_conv(ddsp_ctx* ctx, void* stream, const float* src, int64_t T
 int ddsp_nsf_post(ddsp_ctx* ctx, void* stream, const float* x, const float* w, const float* b, int64_t T, int C, int K,
                   float slope, float* out);
 int ddsp_nsf_mean(ddsp_ctx* ctx, void* stream, const float* a, const float* b, const float* c, int n_terms, int64_t n,
-                  float* out);
+                  float* out, float* out_act, float act_slope);
 int ddsp_log_mel(ddsp_ctx* ctx, void* stream, const float* frames, const float* dft_table, const float* mel_basis,
                  int64_t n_frames, int n_fft, int n_mels, float clip, float* out);
 

@@ -79,9 +79,41 @@ def test_conv1d_building_block(ctx, dev):
             want = want + r.double()
         wp = w.permute(0, 2, 1).reshape(Cout, -1).contiguous()
         got = ctx.conv1d(x.to(dev), wp.to(dev), b.to(dev), k, d, slope, residual=None if r is None else r.to(dev))
-        assert float((got.cpu().double() - want).abs().max()) < 2e-5, (T, Cin, Cout, k, d)
+        # (no activation on load and Cin % 32 == 0: the LDS-DMA kernel in the context's default split-bf16 products)
+        assert float((got.cpu().double() - want).abs().max()) < (6e-5 if slope == 1.0 and Cin % 32 == 0 else 2e-5), (T, Cin, Cout, k, d)
     with pytest.raises(ValueError):
         ctx.conv1d(x.to(dev), wp.to(dev), b.to(dev), 2, 1, 1.0)          # even tap counts are not "same"-paddable
+
+
+@pytest.mark.parametrize("math", ["split_bf16", "fp32"])
+def test_conv1d_on_the_dma_kernel(ctx, dev, math):
+    """Inputs that need no activation on load (in_slope = 1, Cin % 32 == 0) run on the LDS-DMA GEMM with one row pointer per
+    tap: dilations, taps that fall off both ends, row counts that are not tile multiples, wide outputs (the transposed
+    convolutions' 3-tap form), raw and activated outputs - in both product arithmetics of the context."""
+    import hipddsp
+    g = torch.Generator().manual_seed(6)
+    tol = 6e-5 if math == "split_bf16" else 2e-5
+    ctx.set_math(hipddsp.MATH_SPLIT_BF16 if math == "split_bf16" else hipddsp.MATH_FP32)
+    try:
+        for (T, Cin, Cout, k, d, res) in [(2000, 128, 64, 7, 1, False), (777, 32, 32, 11, 5, True), (130, 64, 64, 3, 3, True),
+                                          (5000, 256, 256, 11, 5, True), (61, 256, 1024, 3, 1, True), (9, 32, 16, 7, 5, False)]:
+            x = torch.randn(T, Cin, generator=g)
+            w = torch.randn(Cout, Cin, k, generator=g) / np.sqrt(Cin * k)
+            b = torch.randn(Cout, generator=g)
+            r = torch.randn(T, Cout, generator=g) if res else None
+            want = torch.nn.functional.conv1d(x.double().t()[None], w.double(), b.double(), dilation=d, padding=(k * d - d) // 2)[0].t()
+            if res:
+                want = want + r.double()
+            wp = w.permute(0, 2, 1).reshape(Cout, -1).contiguous()
+            rr = None if r is None else r.to(dev)
+            got, act = ctx.conv1d(x.to(dev), wp.to(dev), b.to(dev), k, d, 1.0, residual=rr, act_slope=0.1)
+            assert float((got.cpu().double() - want).abs().max()) < tol, (T, Cin, Cout, k, d)
+            assert torch.equal(act, torch.nn.functional.leaky_relu(got, 0.1))
+            none, act2 = ctx.conv1d(x.to(dev), wp.to(dev), b.to(dev), k, d, 1.0, residual=rr, want_out=False, act_slope=0.1)
+            assert none is None and torch.equal(act2, act)
+            assert torch.equal(ctx.conv1d(x.to(dev), wp.to(dev), b.to(dev), k, d, 1.0, residual=rr), got)
+    finally:
+        ctx.set_math(hipddsp.MATH_SPLIT_BF16)
 
 
 def test_log_mel_against_oracle(dev, lib_path):
