@@ -59,21 +59,42 @@ __global__ void __launch_bounds__(256) nsf_source_kernel(const float* __restrict
 }
 
 // ---- 1-channel strided convolution: out[t][c] = b[c] + sum_j w[c][j] * src[t*s - pad + j] ----------------------------------------
+// A thread owns channel c for NC_TT consecutive output frames: each tap weight is loaded once and used NC_TT times against
+// the block's source window in the LDS (broadcast reads); 256 / C frame groups share a block when C < 256.  (One thread per
+// output re-read its K weights from rows K floats apart: 1.1 ms of the generator's 8.3 at 860 frames.)
+constexpr int NC_TT = 8;
 __global__ void __launch_bounds__(256) nsf_noise_conv_kernel(const float* __restrict__ src, int64_t T_src,
                                                              const float* __restrict__ w, const float* __restrict__ b,
                                                              int64_t T_out, int C, int K, int stride, int pad,
                                                              float* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= T_out * C) return;
-    const int64_t t = i / C;
-    const int c = (int)(i - t * C);
-    float acc = b[c];
-    const int64_t first = t * stride - pad;
-    for (int j = 0; j < K; ++j) {
-        const int64_t p = first + j;
-        if (p >= 0 && p < T_src) acc = fmaf(w[c * K + j], src[p], acc);
+    extern __shared__ float win[];
+    const int Cb = C < 256 ? C : 256;            // channels per block (blockIdx.y walks wider layers)
+    const int G = 256 / Cb;                      // frame groups per block
+    const int c = blockIdx.y * Cb + threadIdx.x % Cb, gq = threadIdx.x / Cb;
+    const int64_t t_block = (int64_t)blockIdx.x * G * NC_TT;
+    const int wlen = (G * NC_TT - 1) * stride + K;
+    const int64_t first = t_block * stride - pad;
+    for (int i = threadIdx.x; i < wlen; i += 256) {
+        const int64_t p = first + i;
+        win[i] = (p >= 0 && p < T_src) ? src[p] : 0.f;
     }
-    out[i] = acc;
+    __syncthreads();
+    if (gq >= G || c >= C) return;
+    const int64_t t0 = t_block + (int64_t)gq * NC_TT;
+    float acc[NC_TT];
+    const float bc = b[c];
+#pragma unroll
+    for (int i = 0; i < NC_TT; ++i) acc[i] = bc;
+    const float* wr = w + (int64_t)c * K;
+    const float* s0 = win + gq * NC_TT * stride;
+    for (int j = 0; j < K; ++j) {
+        const float wj = wr[j];
+#pragma unroll
+        for (int i = 0; i < NC_TT; ++i) acc[i] = fmaf(wj, s0[i * stride + j], acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NC_TT; ++i)
+        if (t0 + i < T_out) out[(t0 + i) * C + c] = acc[i];
 }
 
 // ---- post: tanh(conv7(leaky_relu(x, 0.01))) with one output channel ------------------------------------------------------------
@@ -107,6 +128,30 @@ __global__ void __launch_bounds__(256) nsf_mean_kernel(const float* __restrict__
         if (out_act) out_act[i] = s > 0.f ? s : s * slope;
     }
 }
+// the same for a split activated output: a thread owns one group of 8 consecutive elements
+__global__ void __launch_bounds__(256) nsf_mean_split_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             const float* __restrict__ c, int n_terms, int64_t groups,
+                                                             float* __restrict__ out, float* __restrict__ out_act, float slope) {
+    for (int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x; gi < groups; gi += (int64_t)gridDim.x * 256) {
+        float x[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 s = *(const f32x4*)(a + 8 * gi + 4 * h);
+            if (n_terms > 1) s += *(const f32x4*)(b + 8 * gi + 4 * h);
+            if (n_terms > 2) s += *(const f32x4*)(c + 8 * gi + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[j] = s[j] / (float)n_terms;
+                x[4 * h + j] = s[j] > 0.f ? s[j] : s[j] * slope;
+            }
+            if (out) *(f32x4*)(out + 8 * gi + 4 * h) = s;
+        }
+        ddsp_u32x4 hi, lo;
+        ddsp_split8(x, hi, lo);
+        *(ddsp_u32x4*)(out_act + 8 * gi) = hi;
+        *(ddsp_u32x4*)(out_act + 8 * gi + 4) = lo;
+    }
+}
 
 // ---- log-mel: out[t][m] = log(max(sum_f mel[m][f] * sqrt(re^2 + im^2 + 1e-9), clip)) ------------------------------------------
 __global__ void __launch_bounds__(256) nsf_magnitude_kernel(const float* __restrict__ spec, int64_t rows, int bins, int ld,
@@ -135,6 +180,7 @@ struct EpiAddBias {   // y = acc + bias[n] (+ res): C = y and / or Cact = leaky_
     int64_t ldc;
     const float* bias;
     float slope;
+    int act_split;   // Cact is written as bf16 hi/lo groups (the A operand layout of gemm::Args::A_split); vector path only
     __device__ __forceinline__ float col(int n) const { return bias ? bias[n] : 0.f; }
     __device__ __forceinline__ void operator()(int, int m, int n, float v, float cb) const {
         const int64_t o = (int64_t)m * ldc + n;
@@ -155,7 +201,10 @@ struct EpiAddBias {   // y = acc + bias[n] (+ res): C = y and / or Cact = leaky_
         if (Cact) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
-            *(f32x4*)(Cact + o) = v;
+            if (act_split)   // the lane 4 further on holds the other half of this group of 8 columns (same row)
+                *(ddsp_u32x4*)(Cact + o) = ddsp_split4_pair(v, (n & 4) != 0, 4);
+            else
+                *(f32x4*)(Cact + o) = v;
         }
     }
 };
@@ -164,7 +213,7 @@ struct EpiAddBias {   // y = acc + bias[n] (+ res): C = y and / or Cact = leaky_
 
 extern "C" int ddsp_conv1d(ddsp_ctx* ctx, void* stream, const float* x, const float* w_packed, const float* bias, int64_t T,
                            int Cin, int Cout, int ktaps, int dil, float in_slope, const float* residual, float* out,
-                           float* out_act, float act_slope) {
+                           float* out_act, float act_slope, const float* w_split, int flags) {
     DDSP_REQUIRE(ctx, ctx && x && w_packed && (out || out_act), "ddsp_conv1d: null argument");
     DDSP_REQUIRE(ctx, T >= 1 && T < (1 << 30) && Cin >= 4 && Cin % 4 == 0 && Cout >= 1 && ktaps >= 1 && ktaps % 2 == 1 &&
                           ktaps <= 63 && dil >= 1 && dil <= 64,
@@ -178,14 +227,26 @@ extern "C" int ddsp_conv1d(ddsp_ctx* ctx, void* stream, const float* x, const fl
     g.ktaps = ktaps;
     g.dil = dil;
     g.in_slope = in_slope;
-    EpiAddBias e{out, out_act, residual, Cout, bias, act_slope};
+    const bool x_split = (flags & DDSP_CONV_X_SPLIT) != 0, act_split = (flags & DDSP_CONV_ACT_SPLIT) != 0;
+    EpiAddBias e{out, out_act, residual, Cout, bias, act_slope, act_split ? 1 : 0};
+    const bool dma = in_slope == 1.0f && Cin % 32 == 0 && gemm::dma_ok(g);
+    DDSP_REQUIRE(ctx, !(x_split || act_split) || (dma && ctx->math != DDSP_MATH_FP32 && w_split && gemm::dma_ok(g)),
+                 "ddsp_conv1d: split operands need the LDS-DMA path (in_slope = 1, Cin % 32 == 0), split-bf16 arithmetic and w_split");
+    DDSP_REQUIRE(ctx, !act_split || (out_act && Cout % 64 == 0 && (Cout <= 256 || Cout % 128 == 0) &&
+                                     (((uintptr_t)out | (uintptr_t)out_act | (uintptr_t)residual) % 16) == 0),
+                 "ddsp_conv1d: a split activated output needs Cout % 64 == 0 and 16-byte aligned tensors");
     auto blocks = [&](int bm, int bn) { return (int64_t)((T + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
     ddsp_prof_begin(ctx, st, PF_OTHER);
-    if (in_slope == 1.0f && Cin % 32 == 0 && gemm::dma_ok(g)) {
+    if (dma) {
         // an input that needs no activation on load: the LDS-DMA kernel with per-tap row pointers, products in the context's
         // arithmetic (split-bf16 by default, ddsp_ctx_set_math(FP32) for fp32 products)
         if (int rc = ddsp_zero_page(ctx, &g.zeros)) return rc;
         g.math = ctx->math == DDSP_MATH_FP32 ? 0 : DDSP_MATH_SPLIT_BF16;
+        if (g.math == DDSP_MATH_SPLIT_BF16 && w_split) {
+            g.B_split = w_split;
+            g.A_split = x_split ? 1 : 0;
+            if (x_split) g.B = w_split;   // (mode 8 reads only the split copies)
+        }
         if (Cout > 256 && blocks(128, 128) >= 512)
             gemm::dma_go<128, 128, EpiAddBias, 2, 8, gemm::A_CONVK>(st, g, 1, e);
         else
@@ -226,8 +287,11 @@ extern "C" int ddsp_nsf_noise_conv(ddsp_ctx* ctx, void* stream, const float* src
     DDSP_REQUIRE(ctx, (T_out - 1) * stride - pad < T_src, "ddsp_nsf_noise_conv: output longer than the source allows");
     hipStream_t st = (hipStream_t)stream;
     DDSP_ENTER_DEVICE(ctx);
-    hipLaunchKernelGGL(nsf_noise_conv_kernel, dim3((unsigned)((T_out * C + 255) / 256)), dim3(256), 0, st, src, T_src, w, b, T_out,
-                       C, K, stride, pad, out);
+    const int Cb = C < 256 ? C : 256, G = 256 / Cb;
+    const size_t lds = ((size_t)(G * NC_TT - 1) * stride + K) * sizeof(float);
+    DDSP_REQUIRE(ctx, lds <= 64 * 1024, "ddsp_nsf_noise_conv: source window too long for the LDS");
+    hipLaunchKernelGGL(nsf_noise_conv_kernel, dim3((unsigned)((T_out + (int64_t)G * NC_TT - 1) / ((int64_t)G * NC_TT)), (unsigned)((C + Cb - 1) / Cb)), dim3(256), lds, st, src,
+                       T_src, w, b, T_out, C, K, stride, pad, out);
     DDSP_LAUNCH_CHECK(ctx);
     return DDSP_OK;
 }
@@ -244,7 +308,7 @@ extern "C" int ddsp_nsf_post(ddsp_ctx* ctx, void* stream, const float* x, const 
 }
 
 extern "C" int ddsp_nsf_mean(ddsp_ctx* ctx, void* stream, const float* a, const float* b, const float* c, int n_terms, int64_t n,
-                             float* out, float* out_act, float act_slope) {
+                             float* out, float* out_act, float act_slope, int flags) {
     DDSP_REQUIRE(ctx, ctx && a && (out || out_act) && n_terms >= 1 && n_terms <= 3 && (n_terms < 2 || b) && (n_terms < 3 || c) && n >= 0,
                  "ddsp_nsf_mean: bad argument");
     if (n == 0) return DDSP_OK;
@@ -252,7 +316,15 @@ extern "C" int ddsp_nsf_mean(ddsp_ctx* ctx, void* stream, const float* a, const 
     DDSP_ENTER_DEVICE(ctx);
     int64_t blocks = (n + 255) / 256;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(nsf_mean_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, b, c, n_terms, n, out, out_act, act_slope);
+    if (flags & DDSP_CONV_ACT_SPLIT) {
+        DDSP_REQUIRE(ctx, out_act && n % 8 == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out | (uintptr_t)out_act) % 16) == 0,
+                     "ddsp_nsf_mean: a split activated output needs n % 8 == 0 and 16-byte aligned tensors");
+        blocks = (n / 8 + 255) / 256;
+        if (blocks > 65536) blocks = 65536;
+        hipLaunchKernelGGL(nsf_mean_split_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, b, c, n_terms, n / 8, out, out_act,
+                           act_slope);
+    } else
+        hipLaunchKernelGGL(nsf_mean_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, b, c, n_terms, n, out, out_act, act_slope);
     DDSP_LAUNCH_CHECK(ctx);
     return DDSP_OK;
 }

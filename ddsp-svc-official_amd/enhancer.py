@@ -126,6 +126,11 @@ def _pack_conv(w):
     return w.permute(0, 2, 1).reshape(w.shape[0], -1).contiguous()
 
 
+def _split_or_none(w_packed):
+    """The packed weight in the split operand layout (hipddsp.presplit), or None where its rows are not whole groups of 8."""
+    return hipddsp.presplit(w_packed) if w_packed.shape[1] % 8 == 0 else None
+
+
 def _pack_conv_transpose(w, stride):
     """ConvTranspose1d weight (Cin, Cout, k), padding (k - stride)//2 -> the 3-tap convolution that produces all `stride`
     output phases at once: (stride*Cout, 3*Cin), row = r*Cout + co, column = tap*Cin + ci, value W[ci][co][r + p - (tap-1)*u]."""
@@ -177,6 +182,7 @@ class Generator(torch.nn.Module):
             raise ValueError("the source module merges 9 harmonics")
         w = _fold_weight_norm(sd, "conv_pre")
         P["pre_w"], P["pre_b"], P["pre_k"] = _pack_conv(w), sd["conv_pre.bias"].float().contiguous(), w.shape[2]
+        P["pre_ws"] = _split_or_none(P["pre_w"])
         ch = h.upsample_initial_channel
         P["ups"], P["noise"], P["res"] = [], [], []
         for i, (u, k) in enumerate(zip(h.upsample_rates, h.upsample_kernel_sizes)):
@@ -184,7 +190,8 @@ class Generator(torch.nn.Module):
             if w.shape[0] != ch // (2 ** i) or w.shape[1] != ch // (2 ** (i + 1)):
                 raise ValueError("upsampling layer shape does not match the config")
             b = sd[f"ups.{i}.bias"].float()
-            P["ups"].append((_pack_conv_transpose(w, u), b.repeat(u).contiguous(), u, w.shape[1]))
+            w_up = _pack_conv_transpose(w, u)
+            P["ups"].append((w_up, _split_or_none(w_up), b.repeat(u).contiguous(), u, w.shape[1]))
             nw = sd[f"noise_convs.{i}.weight"].float()
             if i + 1 < len(h.upsample_rates):
                 s = int(np.prod(h.upsample_rates[i + 1:]))
@@ -201,8 +208,9 @@ class Generator(torch.nn.Module):
                 for t, d in enumerate(dils):
                     w1 = _fold_weight_norm(sd, f"resblocks.{n}.convs1.{t}")
                     w2 = _fold_weight_norm(sd, f"resblocks.{n}.convs2.{t}")
-                    convs.append((_pack_conv(w1), sd[f"resblocks.{n}.convs1.{t}.bias"].float().contiguous(), int(d),
-                                  _pack_conv(w2), sd[f"resblocks.{n}.convs2.{t}.bias"].float().contiguous(), int(k)))
+                    p1, p2 = _pack_conv(w1), _pack_conv(w2)
+                    convs.append((p1, _split_or_none(p1), sd[f"resblocks.{n}.convs1.{t}.bias"].float().contiguous(), int(d),
+                                  p2, _split_or_none(p2), sd[f"resblocks.{n}.convs2.{t}.bias"].float().contiguous(), int(k)))
                 blocks.append(convs)
             P["res"].append(blocks)
         w = _fold_weight_norm(sd, "conv_post")
@@ -243,33 +251,52 @@ class Generator(torch.nn.Module):
         src = c.nsf_source(f0, rand_ini.to(x.device), P["lin_w"], P["lin_b"], self.upp, int(self.h.sampling_rate), 0.1)
         # Every convolution below reads leaky_relu(., 0.1) of its producer's result (models.py:60-62, 251): the producers
         # write that activated copy themselves (`act_slope`), next to the raw result where a residual path or the stage mean
-        # needs it, so that the consumers take their input as it is (in_slope = 1) and run on the LDS-DMA GEMM.
+        # needs it, so that the consumers take their input as it is (in_slope = 1) and run on the LDS-DMA GEMM.  With
+        # split-bf16 products (the context's default) the activated copies of the 64-channel-multiple stages are written in the
+        # split operand layout and the weights were converted at load: those convolutions split nothing in their loops.
+        use_split = c.math == hipddsp.MATH_SPLIT_BF16
+
+        def can_split(cin, cout):
+            """A convolution can write its activated output split when it runs on the DMA kernel itself (Cin % 32 == 0) and
+            its output rows are whole 64-column tiles."""
+            return use_split and cin % 32 == 0 and cout % 64 == 0
+
+        n_mels = x.shape[1]
+        ch0 = int(self.h.upsample_initial_channel)
+        act_s = can_split(n_mels, ch0)               # is the current activated tensor in the split layout?
         _, cur_act = c.conv1d(x[0].t().contiguous(), P["pre_w"], P["pre_b"], P["pre_k"], 1, 1.0, want_out=False,
-                              act_slope=LRELU_SLOPE)                                               # (L, C0)
-        T = L
+                              act_slope=LRELU_SLOPE, w_split=P["pre_ws"] if act_s else None, act_split=act_s)   # (L, C0)
+        T, cin = L, ch0
         cur = None
         for i in range(self.num_upsamples):
-            w_up, b_up, u, cout = P["ups"][i]
+            w_up, w_up_s, b_up, u, cout = P["ups"][i]
             nw, nb, (nk, ns, npad) = P["noise"][i]
             T_out = T * u
             x_source = c.nsf_noise_conv(src, nw, nb, nk, ns, npad, T_out)                          # (T_out, cout)
-            up, up_act = c.conv1d(cur_act, w_up, b_up, 3, 1, 1.0, residual=x_source.reshape(T, u * cout), act_slope=LRELU_SLOPE)
+            s_out = can_split(cin, cout)
+            up, up_act = c.conv1d(cur_act, w_up, b_up, 3, 1, 1.0, residual=x_source.reshape(T, u * cout), act_slope=LRELU_SLOPE,
+                                  w_split=w_up_s if (act_s or s_out) else None, x_split=act_s, act_split=s_out)
             cur, cur_act = up.reshape(T_out, cout), up_act.reshape(T_out, cout)
             T = T_out
             outs = []
+            s = s_out                                 # inside a stage every convolution is cout -> cout
             for convs in P["res"][i]:
                 xr, xr_act = cur, cur_act
-                for t, (w1, b1, d, w2, b2, k) in enumerate(convs):
-                    _, xt_act = c.conv1d(xr_act, w1, b1, k, d, 1.0, want_out=False, act_slope=LRELU_SLOPE)
+                for t, (w1, w1s, b1, d, w2, w2s, b2, k) in enumerate(convs):
+                    _, xt_act = c.conv1d(xr_act, w1, b1, k, d, 1.0, want_out=False, act_slope=LRELU_SLOPE,
+                                         w_split=w1s if s else None, x_split=s, act_split=s)
                     if t + 1 < len(convs):
-                        xr, xr_act = c.conv1d(xt_act, w2, b2, k, 1, 1.0, residual=xr, act_slope=LRELU_SLOPE)
+                        xr, xr_act = c.conv1d(xt_act, w2, b2, k, 1, 1.0, residual=xr, act_slope=LRELU_SLOPE,
+                                              w_split=w2s if s else None, x_split=s, act_split=s)
                     else:
-                        xr = c.conv1d(xt_act, w2, b2, k, 1, 1.0, residual=xr)
+                        xr = c.conv1d(xt_act, w2, b2, k, 1, 1.0, residual=xr, w_split=w2s if s else None, x_split=s)
                 outs.append(xr)
             if i + 1 < self.num_upsamples:
-                _, cur_act = c.nsf_mean(outs, want_out=False, act_slope=LRELU_SLOPE)
+                act_s = use_split and cout % 64 == 0   # the mean kernel writes either layout
+                _, cur_act = c.nsf_mean(outs, want_out=False, act_slope=LRELU_SLOPE, act_split=act_s)
             else:
                 cur = c.nsf_mean(outs)
+            cin = cout
         audio = c.nsf_post(cur, P["post_w"], P["post_b"], P["post_k"], 0.01)
         return audio.reshape(1, 1, -1)
 

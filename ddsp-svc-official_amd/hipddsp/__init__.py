@@ -45,6 +45,21 @@ class ProfEntry(_c.Structure):
                 ("flops_total", _c.c_double), ("bytes_total", _c.c_double)]
 
 
+CONV_X_SPLIT, CONV_ACT_SPLIT = 1, 2
+
+
+def presplit(w):
+    """fp32 matrix (rows, K), K % 8 == 0 -> the same bytes-per-row with every group of 8 values replaced by their 8 bf16 high
+    parts and 8 bf16 remainders (round to nearest even, twice): the pre-split operand layout of the split-bf16 GEMM
+    (gemm::Args::B_split / A_split), bit-identical to what the kernels produce when they split in the loop."""
+    if w.dtype != torch.float32 or w.shape[-1] % 8:
+        raise ValueError("presplit: fp32 with a multiple of 8 columns")
+    g = w.contiguous().reshape(*w.shape[:-1], w.shape[-1] // 8, 8)
+    hi = g.to(torch.bfloat16)
+    lo = (g - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, lo], dim=-1).contiguous().view(torch.float32).reshape(w.shape)
+
+
 FAMILIES = ["phase_scan", "fir_act", "fir_dft_gemm", "ltv_fir", "u2c_prep", "u2c_gemm_conv3", "u2c_gemm_linear",
             "u2c_gemm_feat", "u2c_gemm_ctx", "u2c_gemm_attnout", "u2c_rowwise", "sins_bank", "spectral_ola", "rss_loss",
             "sola", "upsample", "other", "ltv_fir_bwd", "fir_synth_bwd", "u2c_bwd", "optim"]
@@ -76,11 +91,11 @@ SIGNATURES = {
     "ddsp_align_units": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp]),
     "ddsp_resample_length": (_i64, [_i64, _int, _int]),
     "ddsp_resample": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _int, _vp]),
-    "ddsp_conv1d": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _vp, _vp, _vp, _f32]),
+    "ddsp_conv1d": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _vp, _vp, _vp, _f32, _vp, _int]),
     "ddsp_nsf_source": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _f32, _vp]),
     "ddsp_nsf_noise_conv": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _int, _int, _int, _int, _i64, _vp]),
     "ddsp_nsf_post": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _f32, _vp]),
-    "ddsp_nsf_mean": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _i64, _vp, _vp, _f32]),
+    "ddsp_nsf_mean": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _i64, _vp, _vp, _f32, _int]),
     "ddsp_log_mel": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _f32, _vp]),
     "ddsp_adamw_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64]),
     "ddsp_adamw_step_multi": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _i64]),
@@ -421,9 +436,12 @@ class Context:
         return out[0] if flat else out
 
     # -- NSF-HiFiGAN post-net building blocks --------------------------------
-    def conv1d(self, x, w_packed, bias, ktaps, dil, in_slope, residual=None, want_out=True, act_slope=None):
+    def conv1d(self, x, w_packed, bias, ktaps, dil, in_slope, residual=None, want_out=True, act_slope=None, w_split=None,
+               x_split=False, act_split=False):
         """x (T,Cin), w_packed (Cout, ktaps*Cin) -> y (T,Cout) = conv_same(leaky_relu(x, in_slope)) + bias (+ residual).
-        Returns y, or (y | None, leaky_relu(y, act_slope)) when act_slope is given (want_out=False skips y itself)."""
+        Returns y, or (y | None, leaky_relu(y, act_slope)) when act_slope is given (want_out=False skips y itself).
+        Split operands (include/ddsp_amd.h, ddsp_conv1d): `w_split` = presplit(w_packed); `x_split`: x is in the split layout;
+        `act_split`: write the activated copy in it."""
         T, Cin = x.shape
         Cout = w_packed.shape[0]
         if w_packed.shape[1] != ktaps * Cin:
@@ -433,7 +451,8 @@ class Context:
         if out is None and act is None:
             raise ValueError("conv1d: nothing to return")
         self.call("ddsp_conv1d", _ptr(x), _ptr(w_packed), _ptr(bias), T, Cin, Cout, int(ktaps), int(dil), float(in_slope),
-                  _ptr(residual), _ptr(out), _ptr(act), float(act_slope if act_slope is not None else 1.0))
+                  _ptr(residual), _ptr(out), _ptr(act), float(act_slope if act_slope is not None else 1.0), _ptr(w_split),
+                  (CONV_X_SPLIT if x_split else 0) | (CONV_ACT_SPLIT if act_split else 0))
         return out if act_slope is None else (out, act)
 
     def nsf_source(self, f0, rand_ini, lin_w, lin_b, upp, sr, sine_amp=0.1):
@@ -456,15 +475,16 @@ class Context:
         self.call("ddsp_nsf_post", _ptr(x), _ptr(w), _ptr(b), T, C, int(K), float(slope), _ptr(out))
         return out
 
-    def nsf_mean(self, terms, want_out=True, act_slope=None):
-        """Mean of up to three tensors -> out, or (out | None, leaky_relu(out, act_slope)) when act_slope is given."""
+    def nsf_mean(self, terms, want_out=True, act_slope=None, act_split=False):
+        """Mean of up to three tensors -> out, or (out | None, leaky_relu(out, act_slope)) when act_slope is given
+        (`act_split`: that copy in the split operand layout, see conv1d)."""
         a = terms[0]
         out = torch.empty_like(a) if want_out else None
         act = torch.empty_like(a) if act_slope is not None else None
         b = terms[1] if len(terms) > 1 else None
         c = terms[2] if len(terms) > 2 else None
         self.call("ddsp_nsf_mean", _ptr(a), _ptr(b), _ptr(c), len(terms), a.numel(), _ptr(out), _ptr(act),
-                  float(act_slope if act_slope is not None else 1.0))
+                  float(act_slope if act_slope is not None else 1.0), CONV_ACT_SPLIT if act_split else 0)
         return out if act_slope is None else (out, act)
 
     def log_mel(self, frames, dft_table, mel_basis, clip):

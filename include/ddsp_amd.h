@@ -274,7 +274,11 @@ int ddsp_resample(ddsp_ctx* ctx, void* stream, const float* x, int64_t B, int64_
  *   out (T,Cout) and / or, as leaky_relu(y, act_slope), to out_act (either may be NULL): every convolution of the generator
  *   reads an activated input, so a producer that emits it lets the consumer run with in_slope = 1 - and only then (with
  *   Cin % 32 == 0) does the convolution run on the LDS-DMA GEMM in the context's product arithmetic; otherwise on the
- *   register-staged fp32 kernel, which activates while loading.
+ *   register-staged fp32 kernel, which activates while loading.  Split layout (split-bf16 arithmetic only): every group of 8
+ *   consecutive floats of a row replaced by its 8 bf16 high parts and 8 bf16 remainders (32 bytes, same footprint) - what the
+ *   matrix instructions consume; w_split is w_packed in that layout (the host mirror converts once at load), flags say
+ *   whether x arrives so and whether out_act is to be written so (Cout % 64 == 0): a chain of convolutions then converts
+ *   every activation once, where it is produced, instead of once per tile that reads it.
  * ddsp_nsf_source: replaces `SourceModuleHnNSF.forward(f0, upp)` (:180-216 with `SineGen` :106-177, 9 harmonics): f0 (L) Hz per
  *   frame, rand_ini (9) the harmonics' initial phases in cycles (the reference's torch.rand draw, element 0 = 0), lin_w (9),
  *   lin_b (1) of `l_linear`; out (L*upp) = tanh(linear(sine_amp * sin(2 pi cumsum(f0 h / sr)))).
@@ -286,9 +290,11 @@ int ddsp_resample(ddsp_ctx* ctx, void* stream, const float* x, int64_t B, int64_
  * ddsp_log_mel: replaces the spectral half of `STFT.get_mel` (nvSTFT.py:100-117): frames (n_frames, n_fft) of the padded
  *   signal, dft_table (2*ldm, n_fft) rows (w cos, -w sin) per bin with ldm = bins rounded up to 4, mel_basis (n_mels, ldm);
  *   out (n_frames, n_mels) = log(max(mel . sqrt(re^2 + im^2 + 1e-9), clip)). */
+#define DDSP_CONV_X_SPLIT 1   /* x is in the split layout (written so by a producer with DDSP_CONV_ACT_SPLIT) */
+#define DDSP_CONV_ACT_SPLIT 2 /* write out_act in the split layout */
 int ddsp_conv1d(ddsp_ctx* ctx, void* stream, const float* x, const float* w_packed, const float* bias, int64_t T, int Cin,
                 int Cout, int ktaps, int dil, float in_slope, const float* residual, float* out, float* out_act,
-                float act_slope);
+                float act_slope, const float* w_split, int flags);
 int ddsp_nsf_source(ddsp_ctx* ctx, void* stream, const float* f0, const float* rand_ini, const float* lin_w,
                     const float* lin_b, int64_t L, int upp, int sr, float sine_amp, float* out);
 int ddsp_nsf_noise_conv(ddsp_ctx* ctx, void* stream, const float* src, int64_t T_src, const float* w, const float* b, int C,
@@ -296,7 +302,7 @@ int ddsp_nsf_noise_conv(ddsp_ctx* ctx, void* stream, const float* src, int64_t T
 int ddsp_nsf_post(ddsp_ctx* ctx, void* stream, const float* x, const float* w, const float* b, int64_t T, int C, int K,
                   float slope, float* out);
 int ddsp_nsf_mean(ddsp_ctx* ctx, void* stream, const float* a, const float* b, const float* c, int n_terms, int64_t n,
-                  float* out, float* out_act, float act_slope);
+                  float* out, float* out_act, float act_slope, int flags);
 int ddsp_log_mel(ddsp_ctx* ctx, void* stream, const float* frames, const float* dft_table, const float* mel_basis,
                  int64_t n_frames, int n_fft, int n_mels, float clip, float* out);
 

@@ -63,6 +63,28 @@ def test_generator_against_oracle_lengths(dev, lib_path, L):
     assert float((got.cpu() - want).abs().max()) < 1e-4, L
 
 
+@pytest.mark.parametrize("math", ["split_bf16", "fp32"])
+def test_generator_wide_stages(ctx, dev, lib_path, math):
+    """A generator whose first stages have 128 and 64 channels (the shipped one has 256 / 128 / 64): with split-bf16
+    products those stages pass their activations in the split operand layout from convolution to convolution (weights
+    converted at load) - against the oracle generator (= the reference's, tests/golden/ref_enhancer.npz pins it)."""
+    import hipddsp
+    from enhancer import AttrDict, Generator
+    cfg = dict(GC.NSF_CONFIG, upsample_rates=[4, 2, 2], upsample_kernel_sizes=[8, 4, 4], upsample_initial_channel=256, num_mels=32)
+    sd = GC.nsf_state_dict(cfg, seed=77)
+    mel, f0, ri = GC.nsf_inputs(cfg, L=37, seed=78)
+    want = OE.generator(sd, cfg, mel, f0, ri)
+    gen = Generator(AttrDict(cfg), sd)
+    ctx.set_math(hipddsp.MATH_SPLIT_BF16 if math == "split_bf16" else hipddsp.MATH_FP32)
+    try:
+        got = gen(mel.to(dev), f0.to(dev), rand_ini=ri[0])
+    finally:
+        ctx.set_math(hipddsp.MATH_SPLIT_BF16)
+    assert got.shape == want.shape
+    err = float((got.cpu() - want).abs().max())
+    assert err < (3e-4 if math == "split_bf16" else 1e-4), err
+
+
 def test_conv1d_building_block(ctx, dev):
     """`ddsp_conv1d` alone against torch's conv1d (fp64): kernel sizes 1..11, dilations, leaky-ReLU on load, residual."""
     g = torch.Generator().manual_seed(5)
@@ -179,3 +201,19 @@ def test_enhancer_end_to_end(dev, lib_path, tmp_path):
         assert float((got.cpu() - want).abs().max()) < 5e-4, (key, sf)
     with pytest.raises(ValueError):
         Enhancer("other", str(tmp_path / "model"))
+
+
+def test_noise_conv_building_block(ctx, dev):
+    """`ddsp_nsf_noise_conv` (the strided 1-channel convolutions that bring the source signal to each stage's rate) against
+    torch's conv1d in fp64: the shipped geometries (K = 2 s, stride s, padding s / 2; K = 1 at the last stage), channel counts
+    that do and do not divide 256, outputs that end inside a block."""
+    g = torch.Generator().manual_seed(9)
+    for (C, K, s, pad, T_out) in [(256, 128, 64, 32, 77), (128, 16, 8, 4, 1000), (16, 1, 1, 0, 4099), (24, 4, 2, 1, 130), (300, 8, 4, 2, 50)]:
+        T_src = T_out * s
+        src = torch.randn(T_src, generator=g)
+        w = torch.randn(C, K, generator=g) / np.sqrt(K)
+        b = torch.randn(C, generator=g)
+        want = torch.nn.functional.conv1d(src.double()[None, None], w.double()[:, None], b.double(), stride=s, padding=pad)[0].t()[:T_out]
+        got = ctx.nsf_noise_conv(src.to(dev), w.to(dev), b.to(dev), K, s, pad, T_out)
+        assert got.shape == (T_out, C)
+        assert float((got.cpu().double() - want).abs().max()) < 2e-5, (C, K, s)
