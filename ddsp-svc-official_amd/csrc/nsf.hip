@@ -16,6 +16,8 @@
 // the hot path, not part of the benchmarked one).
 #include "gemm_f32.h"
 
+#include <stdlib.h>
+
 #include <math.h>
 
 namespace {
@@ -172,6 +174,169 @@ __global__ void __launch_bounds__(256) nsf_logclamp_kernel(float* __restrict__ x
     if (i < n) x[i] = logf(fmaxf(x[i], clip));
 }
 
+// ---- convolutions of the narrow stages (16 and 32 channels, Cin == Cout) -------------------------------------------------------
+// The implicit-im2col GEMM wastes 50-75 % of a 64-wide tile on them and re-reads the input once per tap from the L2.  Here a
+// wavefront owns 64 consecutive frames: the window it needs (64 + 2 halo rows, activated while it is staged) and the whole
+// weight (k x C x C, transposed to [tap][ci][co]) sit in the LDS, the products run on the fp32 matrix pipe with tiles that
+// fit the channel count exactly - v_mfma_f32_16x16x4_f32 for C = 16 (4 frame tiles per window), v_mfma_f32_32x32x2_f32 for
+// C = 32 (2 frame tiles) -, a weight fragment being fetched once per window and used for every tile.  Window rows are
+// C + 1 floats apart (the 16 / 32 rows a fragment reads then fall on different banks).
+struct ConvSmallArgs {
+    const float* x;
+    const float* w;      // packed (C, k*C), column tap*C + ci
+    const float* bias;
+    const float* res;
+    float* out;
+    float* out_act;
+    int64_t T;
+    int ktaps, dil;
+    float in_slope, act_slope;
+};
+constexpr int CS_TW = 64;   // frames per window
+constexpr int CS_MAX_HALO = 25;   // (k - 1) / 2 * dilation the register prefetch is sized for (11 taps, dilation 5)
+
+template <int C>
+__global__ void __launch_bounds__(256) conv_small_kernel(ConvSmallArgs g) {
+    extern __shared__ float lds[];
+    constexpr int P = C + 1;
+    const int halo = (g.ktaps - 1) / 2 * g.dil, rows = CS_TW + 2 * halo;
+    float* const wl = lds;                                             // [tap][ci][co]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* const win = lds + g.ktaps * C * C + wave * rows * P;        // this wave's window
+    for (int i = threadIdx.x; i < g.ktaps * C * C; i += 256) {         // read in storage order (coalesced), scatter into the LDS
+        const int co = i / (g.ktaps * C), r = i % (g.ktaps * C);       // r = tap*C + ci
+        wl[r * C + co] = g.w[i];
+    }
+    __syncthreads();
+    const int64_t nchunks = (g.T + CS_TW - 1) / CS_TW;
+    // the next window's rows travel global -> registers while the current one feeds the matrix pipe, and are written to the
+    // LDS (activated) after its last read: one wave per SIMD cannot hide a global-load latency per row otherwise
+    constexpr int NV = ((CS_TW + 2 * CS_MAX_HALO) * C / 4 + 63) / 64;
+    const int nvec = rows * C / 4;
+    f32x4 pre[NV];
+    auto load_window = [&](int64_t t0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = (lane + 64 * i) * 4;
+            const int64_t t = t0 - halo + e / C;
+            pre[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (lane + 64 * i < nvec && t >= 0 && t < g.T) pre[i] = *(const f32x4*)(g.x + t * C + e % C);
+        }
+    };
+    auto store_window = [&]() {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = (lane + 64 * i) * 4;
+            if (lane + 64 * i < nvec) {
+                float* p = win + (e / C) * P + e % C;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) p[j] = pre[i][j] > 0.f ? pre[i][j] : pre[i][j] * g.in_slope;
+            }
+        }
+    };
+    const int64_t first = (int64_t)blockIdx.x * 4 + wave, step = (int64_t)gridDim.x * 4;
+    if (first < nchunks) {
+        load_window(first * CS_TW);
+        store_window();
+    }
+    for (int64_t chunk = first; chunk < nchunks; chunk += step) {
+        const int64_t t0 = chunk * CS_TW;
+        const bool more = chunk + step < nchunks;
+        if (more) load_window((chunk + step) * CS_TW);
+        __builtin_amdgcn_wave_barrier();
+        if constexpr (C == 16) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int li = lane & 15, lk = lane >> 4;
+            for (int tap = 0; tap < g.ktaps; ++tap) {
+                const float* wr = wl + (tap * C + lk) * C + li;
+                const float* xr = win + (halo + (tap - (g.ktaps - 1) / 2) * g.dil + li) * P + lk;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const float b = wr[4 * qq * C];
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt)
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[tt * 16 * P + 4 * qq], b, acc[tt], 0, 0, 0);
+                }
+            }
+            // D[4*(l>>4) + r][l & 15]
+            const float bc = g.bias ? g.bias[li] : 0.f;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t t = t0 + tt * 16 + 4 * lk + r;
+                    if (t < g.T) {
+                        const int64_t o = t * C + li;
+                        float y = acc[tt][r] + bc;
+                        if (g.res) y += g.res[o];
+                        if (g.out) g.out[o] = y;
+                        if (g.out_act) g.out_act[o] = y > 0.f ? y : y * g.act_slope;
+                    }
+                }
+        } else {
+            f32x16 acc[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
+            const int li = lane & 31, lk = lane >> 5;
+            for (int tap = 0; tap < g.ktaps; ++tap) {
+                const float* wr = wl + (tap * C + lk) * C + li;
+                const float* xr = win + (halo + (tap - (g.ktaps - 1) / 2) * g.dil + li) * P + lk;
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) {
+                    const float b = wr[2 * kk * C];
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+                        acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[tt * 32 * P + 2 * kk], b, acc[tt], 0, 0, 0);
+                }
+            }
+            // D[(r & 3) + 8*(r >> 2) + 4*(l >> 5)][l & 31]
+            const float bc = g.bias ? g.bias[li] : 0.f;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t t = t0 + tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (t < g.T) {
+                        const int64_t o = t * C + li;
+                        float y = acc[tt][r] + bc;
+                        if (g.res) y += g.res[o];
+                        if (g.out) g.out[o] = y;
+                        if (g.out_act) g.out_act[o] = y > 0.f ? y : y * g.act_slope;
+                    }
+                }
+        }
+        __builtin_amdgcn_wave_barrier();   // the window is re-staged next
+        if (more) store_window();
+    }
+}
+
+static bool conv_small32_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("DDSP_CONV_SMALL32");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+
+template <int C>
+static int launch_conv_small(ddsp_ctx* ctx, hipStream_t st, const ConvSmallArgs& g) {
+    const int halo = (g.ktaps - 1) / 2 * g.dil, rows = CS_TW + 2 * halo;
+    const size_t lds = ((size_t)g.ktaps * C * C + 4 * (size_t)rows * (C + 1)) * sizeof(float);
+    if (lds > 160 * 1024) return ddsp_fail(ctx, DDSP_ERR_ARG, "ddsp_conv1d", "window too long for the LDS");
+    DDSP_ONCE_PER_DEVICE(ctx, DDSP_HIP(ctx, hipFuncSetAttribute((const void*)conv_small_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+    const int64_t nchunks = (g.T + CS_TW - 1) / CS_TW;
+    int64_t blocks = (nchunks + 3) / 4;
+    const int64_t cap = 256 * (lds > 80 * 1024 ? 1 : lds > 53 * 1024 ? 2 : 3);
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((conv_small_kernel<C>), dim3((unsigned)blocks), dim3(256), lds, st, g);
+    return DDSP_OK;
+}
+
 struct EpiAddBias {   // y = acc + bias[n] (+ res): C = y and / or Cact = leaky_relu(y, slope) - the consumer convolutions of the
                       // generator all read an activated input, the residual paths the raw one
     float* C;
@@ -237,7 +402,18 @@ extern "C" int ddsp_conv1d(ddsp_ctx* ctx, void* stream, const float* x, const fl
                  "ddsp_conv1d: a split activated output needs Cout % 64 == 0 and 16-byte aligned tensors");
     auto blocks = [&](int bm, int bn) { return (int64_t)((T + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
     ddsp_prof_begin(ctx, st, PF_OTHER);
-    if (dma) {
+    if (Cin == Cout && Cin == 16 && !x_split && !act_split && ((uintptr_t)x % 16) == 0 && (ktaps - 1) / 2 * dil <= CS_MAX_HALO) {
+        // the narrow last stage: fp32 matrix products on tiles of its own width (conv_small_kernel; 1.87 -> 0.74 ms for the 18
+        // convolutions of the 16-channel stage at 860 frames).  The 32-channel instantiation is kept for measurements
+        // (DDSP_CONV_SMALL32=1): at 1.48 ms per stage it does not beat the LDS-DMA GEMM's 1.28 - one wave per SIMD (105 KB of
+        // LDS per workgroup) on the fp32 matrix pipe reaches a third of its rate.
+        ConvSmallArgs a{x, w_packed, bias, residual, out, out_act, T, ktaps, dil, in_slope, act_slope};
+        if (int rc = launch_conv_small<16>(ctx, st, a)) return rc;
+    } else if (Cin == Cout && Cin == 32 && conv_small32_enabled() && !x_split && !act_split && ((uintptr_t)x % 16) == 0 &&
+               (ktaps - 1) / 2 * dil <= CS_MAX_HALO) {
+        ConvSmallArgs a{x, w_packed, bias, residual, out, out_act, T, ktaps, dil, in_slope, act_slope};
+        if (int rc = launch_conv_small<32>(ctx, st, a)) return rc;
+    } else if (dma) {
         // an input that needs no activation on load: the LDS-DMA kernel with per-tap row pointers, products in the context's
         // arithmetic (split-bf16 by default, ddsp_ctx_set_math(FP32) for fp32 products)
         if (int rc = ddsp_zero_page(ctx, &g.zeros)) return rc;

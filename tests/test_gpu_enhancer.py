@@ -90,7 +90,10 @@ def test_conv1d_building_block(ctx, dev):
     g = torch.Generator().manual_seed(5)
     for (T, Cin, Cout, k, d, slope, res) in [(50, 16, 24, 3, 1, 1.0, False), (333, 32, 32, 7, 3, 0.1, True),
                                              (129, 64, 8, 11, 5, 0.1, False), (7, 4, 4, 1, 1, 0.5, True),
-                                             (2000, 128, 64, 7, 1, 1.0, False)]:
+                                             (2000, 128, 64, 7, 1, 1.0, False),
+                                             # the narrow stages' own kernel (Cin == Cout in {16, 32}): windows of 64 frames
+                                             (4099, 16, 16, 11, 5, 0.1, True), (100, 16, 16, 3, 1, 1.0, False), (64, 16, 16, 1, 1, 0.1, False),
+                                             (1000, 32, 32, 11, 3, 1.0, True), (31, 32, 32, 3, 5, 0.1, False)]:
         x = torch.randn(T, Cin, generator=g)
         w = torch.randn(Cout, Cin, k, generator=g) / np.sqrt(Cin * k)
         b = torch.randn(Cout, generator=g)
