@@ -280,16 +280,17 @@ class Generator(torch.nn.Module):
             T = T_out
             outs = []
             s = s_out                                 # inside a stage every convolution is cout -> cout
+            ws_ok = use_split and cout % 32 == 0      # pre-split weights alone still save the weight half of the in-loop split
             for convs in P["res"][i]:
                 xr, xr_act = cur, cur_act
                 for t, (w1, w1s, b1, d, w2, w2s, b2, k) in enumerate(convs):
                     _, xt_act = c.conv1d(xr_act, w1, b1, k, d, 1.0, want_out=False, act_slope=LRELU_SLOPE,
-                                         w_split=w1s if s else None, x_split=s, act_split=s)
+                                         w_split=w1s if ws_ok else None, x_split=s, act_split=s)
                     if t + 1 < len(convs):
                         xr, xr_act = c.conv1d(xt_act, w2, b2, k, 1, 1.0, residual=xr, act_slope=LRELU_SLOPE,
-                                              w_split=w2s if s else None, x_split=s, act_split=s)
+                                              w_split=w2s if ws_ok else None, x_split=s, act_split=s)
                     else:
-                        xr = c.conv1d(xt_act, w2, b2, k, 1, 1.0, residual=xr, w_split=w2s if s else None, x_split=s)
+                        xr = c.conv1d(xt_act, w2, b2, k, 1, 1.0, residual=xr, w_split=w2s if ws_ok else None, x_split=s)
                 outs.append(xr)
             if i + 1 < self.num_upsamples:
                 act_s = use_split and cout % 64 == 0   # the mean kernel writes either layout
