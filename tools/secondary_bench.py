@@ -87,6 +87,28 @@ t = timeit(lambda: gs64(inp64["units"], inp64["f0"], inp64["volume"], inp64["spk
 t_replay = timeit(lambda: gs64.graph.replay())
 out["CombSub_forward_B64_hip_graph"] = {"ms": t * 1e3, "ms_replay_only": t_replay * 1e3, "samples_per_s": B * Fr * 512 / t,
                                         "x_realtime": B * Fr * 512 / t / 44100}
+# the enhancer's generator at the shipped geometry (seeded weights), 10 s and 2 s of audio
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import enhancer
+import glue_cases as GC
+ecfg = {"resblock": "1", "upsample_rates": [8, 8, 2, 2, 2], "upsample_kernel_sizes": [16, 16, 4, 4, 4],
+        "upsample_initial_channel": 512, "resblock_kernel_sizes": [3, 7, 11],
+        "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5], [1, 3, 5]], "num_mels": 128, "sampling_rate": 44100, "hop_size": 512,
+        "n_fft": 2048, "win_size": 2048, "fmin": 40, "fmax": 16000}
+gen = enhancer.Generator(enhancer.AttrDict(ecfg), GC.nsf_state_dict(ecfg, seed=7))
+for L in (860, 172):
+    mel, ef0, ri = GC.nsf_inputs(ecfg, L=L, seed=8)
+    mel, ef0 = mel.to(dev), ef0.to(dev)
+    t = timeit(lambda: gen(mel, ef0, rand_ini=ri[0]), n=10)
+    out[f"enhancer_generator_{L}_frames"] = {"ms": t * 1e3, "x_realtime": L * 512 / 44100 / t, "tflops_algorithmic": 0.627e-3 * L / t}
+# the causal network (c: true) at the bench batch - sequential attention scans, correct-first
+from ddsp.vocoder import CombSub
+mc = CombSub(44100, 512, cfg["n_mag_allpass"], cfg["n_mag_harmonic"], cfg["n_mag_noise"], 256, cfg["n_spk"], c=True)
+mc.load_state_dict(model64.state_dict(), strict=True)
+mc = mc.to(dev).eval()
+with torch.no_grad():
+    t = timeit(lambda: mc(inp64["units"], inp64["f0"], inp64["volume"], inp64["spk_id"], noise_seed=1), n=5, warm=2)
+out["CombSub_causal_forward_B64"] = {"ms": t * 1e3, "samples_per_s": B * Fr * 512 / t, "x_realtime": B * Fr * 512 / t / 44100}
 # (the model constructors print a banner line each; the JSON goes to its own file when a path is given)
 if len(sys.argv) > 1:
     json.dump(out, open(sys.argv[1], "w"), indent=1)
