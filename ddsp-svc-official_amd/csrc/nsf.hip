@@ -314,6 +314,140 @@ __global__ void __launch_bounds__(256) conv_small_kernel(ConvSmallArgs g) {
     }
 }
 
+// ---- the 32-channel stage with split-bf16 products -----------------------------------------------------------------------------
+// Same ownership as conv_small_kernel (a wavefront owns 64 frames, window + whole weight in the LDS), but window and weight
+// are converted to bf16 hi / lo halves ONCE while they are staged - row image [32 hi | 32 lo], 144 bytes apart so that the
+// 16-byte fragment reads of 16 consecutive rows fall on different banks - and every fp32 product is three
+// v_mfma_f32_32x32x16_bf16 (lo*hi + hi*lo + hi*hi): 12 matrix instructions of 32 cycles per tap and window instead of 32 of
+// 64 cycles on the fp32 pipe, which leaves the kernel to the memory system (four 28 MB tensors per convolution).
+constexpr int CB_PITCH = 144 / 4;   // dwords per row image
+typedef __bf16 nsf_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v){a, b}, bf16x2v));
+    const f32x2v rem = (f32x2v){a, b} - (f32x2v){__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(rem, bf16x2v));
+}
+__global__ void __launch_bounds__(256) conv_small32_bf16_kernel(ConvSmallArgs g) {
+    constexpr int C = 32;
+    extern __shared__ uint32_t ldsu[];
+    const int halo = (g.ktaps - 1) / 2 * g.dil, rows = CS_TW + 2 * halo;
+    uint32_t* const wl = ldsu;                                          // [tap][co] row images of the 32 ci
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* const win = ldsu + g.ktaps * C * CB_PITCH + wave * rows * CB_PITCH;
+    for (int i4 = threadIdx.x; i4 < g.ktaps * C * C / 4; i4 += 256) {   // four consecutive ci of one (co, tap)
+        const int e = i4 * 4, co = e / (g.ktaps * C), r = e % (g.ktaps * C), tap = r / C, ci = r % C;
+        const f32x4 v = *(const f32x4*)(g.w + e);
+        uint32_t h0, l0, h1, l1;
+        split2(v[0], v[1], h0, l0);
+        split2(v[2], v[3], h1, l1);
+        uint32_t* p = wl + (tap * C + co) * CB_PITCH + ci / 2;
+        p[0] = h0;
+        p[1] = h1;
+        p[16] = l0;
+        p[17] = l1;
+    }
+    __syncthreads();
+    const int64_t nchunks = (g.T + CS_TW - 1) / CS_TW;
+    constexpr int NV = ((CS_TW + 2 * CS_MAX_HALO) * C / 4 + 63) / 64;
+    const int nvec = rows * C / 4;
+    f32x4 pre[NV];
+    auto load_window = [&](int64_t t0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = (lane + 64 * i) * 4;
+            const int64_t t = t0 - halo + e / C;
+            pre[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (lane + 64 * i < nvec && t >= 0 && t < g.T) pre[i] = *(const f32x4*)(g.x + t * C + e % C);
+        }
+    };
+    auto store_window = [&]() {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = (lane + 64 * i) * 4;
+            if (lane + 64 * i < nvec) {
+                f32x4 v = pre[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * g.in_slope;
+                uint32_t h0, l0, h1, l1;
+                split2(v[0], v[1], h0, l0);
+                split2(v[2], v[3], h1, l1);
+                uint32_t* p = win + (e / C) * CB_PITCH + (e % C) / 2;
+                p[0] = h0;
+                p[1] = h1;
+                p[16] = l0;
+                p[17] = l1;
+            }
+        }
+    };
+    const int64_t first = (int64_t)blockIdx.x * 4 + wave, step = (int64_t)gridDim.x * 4;
+    if (first < nchunks) {
+        load_window(first * CS_TW);
+        store_window();
+    }
+    const int li = lane & 31, lh = lane >> 5;
+    for (int64_t chunk = first; chunk < nchunks; chunk += step) {
+        const int64_t t0 = chunk * CS_TW;
+        const bool more = chunk + step < nchunks;
+        if (more) load_window((chunk + step) * CS_TW);
+        __builtin_amdgcn_wave_barrier();
+        f32x16 acc[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
+        for (int tap = 0; tap < g.ktaps; ++tap) {
+            // fragment of lane (i, h) in k-step s: ci 16 s + 8 h .. + 7 = dwords 8 s + 4 h .. + 3 of the hi half, + 16 for lo
+            const uint32_t* wr = wl + (tap * C + li) * CB_PITCH + 4 * lh;
+            const uint32_t* xr = win + (halo + (tap - (g.ktaps - 1) / 2) * g.dil + li) * CB_PITCH + 4 * lh;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const nsf_bf16x8 bh = __builtin_bit_cast(nsf_bf16x8, *(const ddsp_u32x4*)(wr + 8 * s));
+                const nsf_bf16x8 bl = __builtin_bit_cast(nsf_bf16x8, *(const ddsp_u32x4*)(wr + 8 * s + 16));
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const nsf_bf16x8 ah = __builtin_bit_cast(nsf_bf16x8, *(const ddsp_u32x4*)(xr + tt * 32 * CB_PITCH + 8 * s));
+                    const nsf_bf16x8 al = __builtin_bit_cast(nsf_bf16x8, *(const ddsp_u32x4*)(xr + tt * 32 * CB_PITCH + 8 * s + 16));
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[tt], 0, 0, 0);
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[tt], 0, 0, 0);
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[tt], 0, 0, 0);
+                }
+            }
+        }
+        // D[(r & 3) + 8*(r >> 2) + 4*(l >> 5)][l & 31]: row = frame (the A operand's row), column = co
+        const float bc = g.bias ? g.bias[li] : 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t t = t0 + tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (t < g.T) {
+                    const int64_t o = t * C + li;
+                    float y = acc[tt][r] + bc;
+                    if (g.res) y += g.res[o];
+                    if (g.out) g.out[o] = y;
+                    if (g.out_act) g.out_act[o] = y > 0.f ? y : y * g.act_slope;
+                }
+            }
+        __builtin_amdgcn_wave_barrier();
+        if (more) store_window();
+    }
+}
+
+static int launch_conv_small32_bf16(ddsp_ctx* ctx, hipStream_t st, const ConvSmallArgs& g) {
+    const int halo = (g.ktaps - 1) / 2 * g.dil, rows = CS_TW + 2 * halo;
+    const size_t lds = ((size_t)g.ktaps * 32 + 4 * (size_t)rows) * CB_PITCH * sizeof(uint32_t);
+    if (lds > 160 * 1024) return ddsp_fail(ctx, DDSP_ERR_ARG, "ddsp_conv1d", "window too long for the LDS");
+    DDSP_ONCE_PER_DEVICE(ctx, DDSP_HIP(ctx, hipFuncSetAttribute((const void*)conv_small32_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+    const int64_t nchunks = (g.T + CS_TW - 1) / CS_TW;
+    int64_t blocks = (nchunks + 3) / 4;
+    const int64_t cap = 256 * (lds > 80 * 1024 ? 1 : lds > 53 * 1024 ? 2 : 3);
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(conv_small32_bf16_kernel, dim3((unsigned)blocks), dim3(256), lds, st, g);
+    return DDSP_OK;
+}
+
 static bool conv_small32_enabled() {
     static int v = -1;
     if (v < 0) {
@@ -409,6 +543,11 @@ extern "C" int ddsp_conv1d(ddsp_ctx* ctx, void* stream, const float* x, const fl
         // LDS per workgroup) on the fp32 matrix pipe reaches a third of its rate.
         ConvSmallArgs a{x, w_packed, bias, residual, out, out_act, T, ktaps, dil, in_slope, act_slope};
         if (int rc = launch_conv_small<16>(ctx, st, a)) return rc;
+    } else if (Cin == Cout && Cin == 32 && ctx->math != DDSP_MATH_FP32 && !conv_small32_enabled() && !x_split && !act_split &&
+               (((uintptr_t)x | (uintptr_t)w_packed) % 16) == 0 && (ktaps - 1) / 2 * dil <= CS_MAX_HALO) {
+        // the 32-channel stage in split-bf16 arithmetic: the narrow kernel with bf16 fragments
+        ConvSmallArgs a{x, w_packed, bias, residual, out, out_act, T, ktaps, dil, in_slope, act_slope};
+        if (int rc = launch_conv_small32_bf16(ctx, st, a)) return rc;
     } else if (Cin == Cout && Cin == 32 && conv_small32_enabled() && !x_split && !act_split && ((uintptr_t)x % 16) == 0 &&
                (ktaps - 1) / 2 * dil <= CS_MAX_HALO) {
         ConvSmallArgs a{x, w_packed, bias, residual, out, out_act, T, ktaps, dil, in_slope, act_slope};

@@ -104,8 +104,10 @@ def test_conv1d_building_block(ctx, dev):
             want = want + r.double()
         wp = w.permute(0, 2, 1).reshape(Cout, -1).contiguous()
         got = ctx.conv1d(x.to(dev), wp.to(dev), b.to(dev), k, d, slope, residual=None if r is None else r.to(dev))
-        # (no activation on load and Cin % 32 == 0: the LDS-DMA kernel in the context's default split-bf16 products)
-        assert float((got.cpu().double() - want).abs().max()) < (6e-5 if slope == 1.0 and Cin % 32 == 0 else 2e-5), (T, Cin, Cout, k, d)
+        # (split-bf16 products, the context's default: the LDS-DMA kernel when no activation on load is asked and
+        # Cin % 32 == 0, the narrow kernel with bf16 fragments for 32 -> 32 channels; fp32 products elsewhere)
+        split = (slope == 1.0 and Cin % 32 == 0) or Cin == Cout == 32
+        assert float((got.cpu().double() - want).abs().max()) < (6e-5 if split else 2e-5), (T, Cin, Cout, k, d)
     with pytest.raises(ValueError):
         ctx.conv1d(x.to(dev), wp.to(dev), b.to(dev), 2, 1, 1.0)          # even tap counts are not "same"-paddable
 
