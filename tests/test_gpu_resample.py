@@ -18,7 +18,10 @@ def _signal(seed, B, T, sr):
 
 @pytest.mark.parametrize("orig,new,lpw,T", [(44100, 48000, 128, 44544), (48000, 44100, 128, 20000), (44100, 16000, 128, 30001),
                                             (44100, 46700, 128, 9000), (16000, 44100, 6, 777), (44100, 22050, 16, 4),
-                                            (32000, 48000, 64, 1)])
+                                            (32000, 48000, 64, 1),
+                                            # reduced rates 4409 / 4800: the window of 8 frames does not fit the LDS -> the
+                                            # one-output-per-thread kernel; (7, 3): a table narrower than a workgroup
+                                            (44090, 48000, 16, 9000), (7, 3, 4, 100), (44100, 52400, 128, 30000)])
 def test_resample_against_fp64(ctx, dev, orig, new, lpw, T):
     x = _signal(T, 2, T, orig)
     want = OR.resample(x, orig, new, lpw, dtype=torch.float64)
