@@ -1491,8 +1491,12 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
     // GEMM loops.  The weights are packed as bf16 hi/lo groups by the preparation launch (B_split) and the producers of
     // the A operands (GroupNorm+LeakyReLU, the LayerNorms, the attention kernel) write them in that layout (A_split);
     // conv1 reads the caller's fp32 units: it alone still splits A in the kernel.
-    const bool presplit = lin_math == DDSP_MATH_SPLIT_BF16 && ctx->math != 4 && fuse_glu && M >= 8192 && w.n_unit % 32 == 0 &&
-                          w.n_unit + 32 <= DDSP_ZERO_FLOATS && w.n_out >= 256 && ((uintptr_t)in.units % 16) == 0;
+    // (presplit_w: the weights alone, at any batch size - every GEMM of the inference forward runs the DMA kernel now, which
+    // then splits only its A operand in the loop (mode 7); presplit: the activations too, from the size at which the fused-GLU
+    // tiling is used)
+    const bool presplit_w = lin_math == DDSP_MATH_SPLIT_BF16 && ctx->math != 4 && w.n_unit % 32 == 0 &&
+                            w.n_unit + 32 <= DDSP_ZERO_FLOATS && w.n_out >= 256 && ((uintptr_t)in.units % 16) == 0;
+    const bool presplit = presplit_w && fuse_glu && M >= 8192;
     const bool attn_bf16 = !bf.l[0].pre && lin_math == DDSP_MATH_SPLIT_BF16 && B * H >= 256 && !w.causal;
     const int asplit = presplit ? 1 : 0;
     {   // weight preparation, one launch (u2c_prepare_kernel)
@@ -1507,7 +1511,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         pa.bglu = bf.bglu;
         pa.wout = bf.wout;
         pa.wpw2 = bf.wpw2;
-        pa.split = asplit;
+        pa.split = presplit_w ? 1 : 0;
         pa.qkv_blocks = 192;
         pa.glu_blocks = 128;
         pa.copy_blocks = 32;
@@ -1516,11 +1520,11 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         pa.end[2] = pa.end[1] + (w.n_out + 3) / 4;
         pa.end[3] = pa.end[2] + 3 * pa.qkv_blocks;
         pa.end[4] = pa.end[3] + (fuse_glu ? 3 * pa.glu_blocks : 0);
-        pa.end[5] = pa.end[4] + (presplit ? 6 * pa.copy_blocks : 0);
+        pa.end[5] = pa.end[4] + (presplit_w ? 6 * pa.copy_blocks : 0);
         pa.end[6] = pa.end[5] + 48;
         pa.wdw = bf.wdw;
         PROF(PF_U2C_PREP, 0, 8.0 * (n_w1 + n_w2 + n_wh + 3.0 * 3 * INNER * D + (fuse_glu ? 3.0 * 2 * INNER * D : 0.0) +
-                                    (presplit ? 6.0 * D * INNER : 0.0)),
+                                    (presplit_w ? 6.0 * D * INNER : 0.0)),
              hipLaunchKernelGGL(u2c_prepare_kernel, dim3((unsigned)pa.end[6]), dim3(256), 0, st, pa));
         if (attn_bf16)   // the three projection matrices as bf16 pieces for the split attention kernels, one launch
             PROF(PF_U2C_PREP, 0, 3.0 * (4.0 * NF * DH + PERFORMER_P3_BYTES),
@@ -1529,7 +1533,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
     // with B_split the GEMM reads ONLY the split copy: both pointers name the same packed matrix
     auto set_b = [&](gemm::Args& g, const float* packed, int a_is_split) {
         g.math = lin_math;
-        if (presplit) {
+        if (presplit_w) {
             g.B = packed;
             g.B_split = packed;
             g.A_split = a_is_split;
