@@ -1496,7 +1496,12 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
     // tiling is used)
     const bool presplit_w = lin_math == DDSP_MATH_SPLIT_BF16 && ctx->math != 4 && w.n_unit % 32 == 0 &&
                             w.n_unit + 32 <= DDSP_ZERO_FLOATS && w.n_out >= 256 && ((uintptr_t)in.units % 16) == 0;
-    const bool presplit = presplit_w && fuse_glu && M >= 8192;
+    static int64_t presplit_min_rows = -1;   // DDSP_U2C_PRESPLIT_MIN_ROWS: measurement aid
+    if (presplit_min_rows < 0) {
+        const char* e = getenv("DDSP_U2C_PRESPLIT_MIN_ROWS");
+        presplit_min_rows = e ? atoll(e) : 8192;
+    }
+    const bool presplit = presplit_w && fuse_glu && M >= presplit_min_rows;
     const bool attn_bf16 = !bf.l[0].pre && lin_math == DDSP_MATH_SPLIT_BF16 && B * H >= 256 && !w.causal;
     const int asplit = presplit ? 1 : 0;
     {   // weight preparation, one launch (u2c_prepare_kernel)
