@@ -407,14 +407,30 @@ struct EpiEmbed {
 };
 
 // ---- LayerNorm over 256 channels, one wave per row (4 channels per lane) ----------------------------
+// Small batches (K-split GEMMs, see u2c_forward): the row to normalise is first completed here,
+//   x_out[m] = x[m] + bias + sum_s part[s][m]   (the residual GEMM's epilogue, deferred: its K range was cut into KS_SPLITS
+// workgroups per tile that each stored a partial product), written back for the next residual and then normalised.
+struct LnPending {
+    const float* part;   // [KS_SPLITS][rows][D] or null
+    const float* bias;
+    float* x_out;
+};
+constexpr int KS_SPLITS = 4;
+constexpr int KS_MAX_ROWS = 256;   // up to 4 row tiles x 4 column tiles x 4 splits = 64 workgroups (344 rows measured slower than whole-K launches)
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int64_t rows,
-                                                        float* __restrict__ out, int split) {
+                                                        float* __restrict__ out, int split, LnPending pend = LnPending{nullptr, nullptr, nullptr}) {
     // split != 0: the row is written as bf16 hi/lo groups (A operand of a split-bf16 GEMM): lanes 2j, 2j+1 own one group
     const int lane = threadIdx.x & 63;
     const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= rows) return;
-    const f32x4 v = *(const f32x4*)(x + m * D + lane * 4);
+    f32x4 v = *(const f32x4*)(x + m * D + lane * 4);
+    if (pend.part) {
+        f32x4 p0 = *(const f32x4*)(pend.part + m * D + lane * 4), p1 = *(const f32x4*)(pend.part + (rows + m) * D + lane * 4);
+        const f32x4 p2 = *(const f32x4*)(pend.part + (2 * rows + m) * D + lane * 4), p3 = *(const f32x4*)(pend.part + (3 * rows + m) * D + lane * 4);
+        v = v + (((p0 + p1) + (p2 + p3)) + *(const f32x4*)(pend.bias + lane * 4));
+        *(f32x4*)(pend.x_out + m * D + lane * 4) = v;
+    }
     const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / D);
     f32x4 d;
     float ss = 0.f;
@@ -1369,7 +1385,7 @@ struct LayerBufs {
     float *x_in, *y, *q, *k, *v, *qf, *kf, *ks, *cx, *dinv, *attn, *x_mid, *y2, *g1, *glu, *pre, *dwo, *x_out;
 };
 struct U2CBufs {
-    float *w1, *w2, *wh, *wqkv, *bqkv, *wglu, *bglu, *wdw, *wout, *wpw2, *p3, *t1, *t2, *gst, *y_final;
+    float *w1, *w2, *wh, *wqkv, *bqkv, *wglu, *bglu, *wdw, *wout, *wpw2, *p3, *t1, *t2, *gst, *y_final, *kpart;
     LayerBufs l[3];
 };
 
@@ -1419,6 +1435,7 @@ static void plan_forward(Arena& a, U2CBufs& bf, const ddsp_u2c_weights& w, int64
     bf.t2 = a.get(M * D);
     bf.gst = a.get((size_t)B * 4 * 2);
     bf.y_final = a.get(M * D);
+    bf.kpart = a.get((size_t)KS_SPLITS * (M <= KS_MAX_ROWS ? M : 1) * D);   // K-split partial products (small batches only)
     auto one = [&](LayerBufs& L, float* x_in) {
         L.x_in = x_in;
         L.y = a.get(M * D);
@@ -1504,6 +1521,32 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
     const bool presplit = presplit_w && fuse_glu && M >= presplit_min_rows;
     const bool attn_bf16 = !bf.l[0].pre && lin_math == DDSP_MATH_SPLIT_BF16 && B * H >= 256 && !w.causal;
     const int asplit = presplit ? 1 : 0;
+    // A handful of rows (the real-time block: 87): the N = 256, K = 512 residual GEMMs (out-projection, pw2) would run on 8
+    // workgroups walking 16 k-steps each.  Their K range is cut over KS_SPLITS workgroups per tile instead (32-96 workgroups,
+    // 4 k-steps each, partial products stored) and the sum + bias + residual is formed by the LayerNorm that follows.
+    static int ksplit_on = -1;
+    if (ksplit_on < 0) {
+        const char* e = getenv("DDSP_U2C_KSPLIT");   // measurement aid: 0 restores whole-K launches
+        ksplit_on = (e && e[0] == '0') ? 0 : 1;
+    }
+    const bool ksplit = ksplit_on && !bf.l[0].pre && M <= KS_MAX_ROWS;
+    LnPending pending{nullptr, nullptr, nullptr};
+    auto residual_gemm = [&](gemm::Args g, const float* x_res, float* x_dst, const float* bias) {
+        // x_dst = x_res + A B^T + bias, now or (ksplit) when the next LayerNorm reads it
+        if (ksplit && gemm::dma_ok(g) && g.K % (32 * KS_SPLITS) == 0) {
+            const int kc = g.K / KS_SPLITS;
+            g.K = kc;
+            g.sA_hi = kc;
+            g.sB_hi = kc;
+            gemm::EpiStore e{bf.kpart, D, nullptr, 1, M * D, 0};
+            gemm::dma_go<64, 64, gemm::EpiStore, 4, 4>(st, g, KS_SPLITS, e);
+            pending = LnPending{bf.kpart, bias, x_dst};
+            return x_res;   // the LayerNorm reads the residual from here
+        }
+        gemm::EpiResidual e{x_dst, x_res, D, bias};
+        gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e);
+        return (const float*)x_dst;
+    };
     {   // weight preparation, one launch (u2c_prepare_kernel)
         PrepArgs pa;
         pa.w = w;
@@ -1576,12 +1619,14 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
     DDSP_LAUNCH_CHECK(ctx);
 
     const unsigned rows_g = (unsigned)ceil_div64(M, 4), rows8_g = (unsigned)ceil_div64(M8, 4);
+    const float* ln_src = nullptr;   // where the next LayerNorm finds the residual stream (null: the layer's own x_in)
     for (int l = 0; l < 3; ++l) {
         const ddsp_u2c_layer& L = w.layer[l];
         LayerBufs& b = bf.l[l];
         // -- x_mid = x_in + to_out(linear_attention(LN(x_in)))
         PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
-             hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, b.x_in, L.norm_w, L.norm_b, M, b.y, asplit));
+             hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, ln_src ? ln_src : b.x_in, L.norm_w, L.norm_b, M, b.y, asplit, pending));
+        pending = LnPending{nullptr, nullptr, nullptr};
         {
             gemm::Args g = gemm::make(b.y, D, bf.wqkv + (size_t)l * 3 * INNER * D, D, iM, 3 * INNER, D);
             set_b(g, bf.wqkv + (size_t)l * 3 * INNER * D, asplit);
@@ -1663,13 +1708,12 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         {
             gemm::Args g = gemm::make(b.attn, INNER, L.out_w, INNER, iM, D, INNER);
             set_b(g, bf.wout + (size_t)l * D * INNER, attn_bf16 ? asplit : 0);
-            gemm::EpiResidual e{b.x_mid, b.x_in, D, L.out_b};
-            PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * D * INNER, 4.0 * M * (INNER + 2 * D),
-                 (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
+            PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * D * INNER, 4.0 * M * (INNER + 2 * D), ln_src = residual_gemm(g, b.x_in, b.x_mid, L.out_b));
         }
         // -- x_out = x_mid + conv_module(x_mid)
         PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
-             hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, b.x_mid, L.cm_ln_w, L.cm_ln_b, M, b.y2, asplit));
+             hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, ln_src, L.cm_ln_w, L.cm_ln_b, M, b.y2, asplit, pending));
+        pending = LnPending{nullptr, nullptr, nullptr};
         if (fuse_glu) {
             gemm::Args g = gemm::make(b.y2, D, bf.wglu + (size_t)l * 2 * INNER * D, D, iM, 2 * INNER, D);
             set_b(g, bf.wglu + (size_t)l * 2 * INNER * D, asplit);
@@ -1698,16 +1742,14 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         {
             gemm::Args g = gemm::make(b.dwo, INNER, L.cm_pw2_w, INNER, iM, D, INNER);
             set_b(g, bf.wpw2 + (size_t)l * D * INNER, asplit);
-            gemm::EpiResidual e{b.x_out, b.x_mid, D, L.cm_pw2_b};
-            PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * D * INNER, 4.0 * M * (INNER + 2 * D),
-                 (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
+            PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * D * INNER, 4.0 * M * (INNER + 2 * D), ln_src = residual_gemm(g, b.x_mid, b.x_out, L.cm_pw2_b));
         }
         DDSP_LAUNCH_CHECK(ctx);
     }
     // ---- LayerNorm -> weight-normed head ----
     PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
-         hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, bf.l[2].x_out, w.final_ln_w, w.final_ln_b,
-                            M, bf.y_final, asplit));
+         hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, ln_src, w.final_ln_w, w.final_ln_b,
+                            M, bf.y_final, asplit, pending));
     {
         gemm::Args g = gemm::make(bf.y_final, D, bf.wh, D, iM, w.n_out, D);
         set_b(g, bf.wh, asplit);
