@@ -68,6 +68,9 @@ struct Args {
     // x, x + 8, ... with ALL their column tiles, so the A rows of a row block are fetched into one L2 instead of eight
     // (the leftover tiles_m % 8 row blocks are dealt round-robin as before).
     int xcd;
+    // DMA kernel: batch index z also starts its k range kz floats into A's and B's rows (the taps of an implicit-im2col
+    // convolution follow from the shifted k): a K-split whose partial products the caller's epilogue stores per z
+    int kz;
 };
 
 constexpr int BK = 32;
@@ -418,6 +421,7 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ?
     const float* src_m1[PA];                 // taps 0 and 2 (tap 1 lives in src[])
     const float* src_p1[PA];
     int conv_f[PA];                          // A_CONVK: frame (inside its utterance) of each A row this wave fetches
+    int kbase_cur = 0;                       // Args::kz: k offset of the tile whose pieces are being issued
     auto tile_src = [&](int tile, const float* (&src)[PPW]) {
         const int per_z = tiles_m * tiles_n;
         int z = tile / per_z, rem = tile - z * per_z;
@@ -430,6 +434,7 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ?
         }
         const float* A = g.A + (int64_t)(z / g.zdiv) * g.sA_hi + (int64_t)(z % g.zdiv) * g.sA_lo;
         const float* B = g.B + (int64_t)(z / g.zdiv) * g.sB_hi + (int64_t)(z % g.zdiv) * g.sB_lo;
+        kbase_cur = z * g.kz;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int piece = wave + NW * i;
@@ -464,7 +469,7 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ?
         }
     };
     auto issue = [&](const float* const (&src)[PPW], int kt, int stage) {
-        int tap = 1, koff = kt * 32;
+        int tap = 1, koff = kt * 32 + kbase_cur;
         if constexpr (A_MODE == A_CONV3 || A_MODE == A_CONVK) {
             tap = koff / g.Cin;
             koff -= tap * g.Cin;
@@ -473,7 +478,7 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ?
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int piece = wave + NW * i;
-            const float* p = src[i] + kt * 32;
+            const float* p = src[i] + kt * 32 + kbase_cur;
             if constexpr (A_MODE == A_CONV3) {
                 if (i < PA) p = (tap == 0 ? src_m1[i < PA ? i : 0] : tap == 1 ? src[i] : src_p1[i < PA ? i : 0]) + koff;
             }
@@ -889,6 +894,7 @@ inline Args make(const float* A, int64_t lda, const float* B, int64_t ldb, int M
     g.B_split = nullptr;
     g.A_split = 0;
     g.xcd = -1;   // decided by dma_go from the product arithmetic (see there)
+    g.kz = 0;
     return g;
 }
 

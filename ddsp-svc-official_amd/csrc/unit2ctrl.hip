@@ -217,15 +217,30 @@ __global__ void __launch_bounds__(256) u2c_prepare_kernel(PrepArgs a) {
 
 // ---- GroupNorm(4, 256) over (64 channels x all frames) per utterance + LeakyReLU -------------------
 constexpr int GN_LANES = 16;   // frame lanes (waves) per block of the statistics kernel
-__global__ void __launch_bounds__(64 * GN_LANES) groupnorm_stats_kernel(const float* __restrict__ x, int Fr,
-                                                                       float* __restrict__ stats) {
+// part != null (small batches, conv1 run as a K-split): x[row][ch] is first completed as bias[ch] + sum_s part[s][row][ch]
+// (rows = all frames of the call) and written back for the normalisation pass.
+__global__ void __launch_bounds__(64 * GN_LANES) groupnorm_stats_kernel(float* __restrict__ x, int Fr, float* __restrict__ stats,
+                                                                       const float* __restrict__ part = nullptr,
+                                                                       const float* __restrict__ bias = nullptr, int64_t rows = 0) {
     // block = (group g, utterance b); 1024 threads = 64 channels x 16 frame lanes.  (With 4 frame lanes every thread
     // walked 43 dependent loads, one in flight at a time: 14 us for 11 MB.  The sums are combined in a fixed order.)
     const int g = blockIdx.x, b = blockIdx.y;
     const int c = threadIdx.x & 63, fl = threadIdx.x >> 6;
-    const float* base = x + ((int64_t)b * Fr) * D + g * 64 + c;
+    float* base = x + ((int64_t)b * Fr) * D + g * 64 + c;
     double s = 0.0, ss = 0.0;
     int f = fl;
+    if (part) {
+        const float* pb = part + ((int64_t)b * Fr) * D + g * 64 + c;
+        const float bc = bias[g * 64 + c];
+        for (int ff = fl; ff < Fr; ff += GN_LANES) {
+            const int64_t o = (int64_t)ff * D;
+            const float v = ((pb[o] + pb[rows * D + o]) + (pb[2 * rows * D + o] + pb[3 * rows * D + o])) + bc;
+            base[o] = v;
+            s += (double)v;
+            ss += (double)v * (double)v;
+        }
+        f = Fr;
+    }
     for (; f + GN_LANES < Fr; f += 2 * GN_LANES) {          // two independent loads per trip
         const double v0 = (double)base[(int64_t)f * D], v1 = (double)base[(int64_t)(f + GN_LANES) * D];
         s += v0 + v1;
@@ -348,6 +363,7 @@ struct EpiEmbed {
     MixArgs mix;
     int Fr;
     int* err;
+    int64_t zstride;            // K-split launches: batch z stores its partial product at out + z * zstride, z = 0 adds bias + embeddings
     __device__ __forceinline__ float col(int n) const { return bias[n]; }
     __device__ __forceinline__ float embed(int m, int n, float v) const {
         const float lf0 = logf(1.0f + __fdiv_rn(f0[m], 700.0f));
@@ -366,13 +382,17 @@ struct EpiEmbed {
         }
         return v;
     }
-    __device__ __forceinline__ void operator()(int, int m, int n, float v, float cb) const {
-        out[(int64_t)m * D + n] = embed(m, n, v + cb);
+    __device__ __forceinline__ void operator()(int z, int m, int n, float v, float cb) const {
+        out[z * zstride + (int64_t)m * D + n] = z == 0 ? embed(m, n, v + cb) : v;
     }
     static constexpr bool kStore4 = true;
-    __device__ __forceinline__ bool vec_ok() const { return ((uintptr_t)out % 16) == 0; }
-    __device__ __forceinline__ void store4(int, int m, int n, f32x4 v) const {
+    __device__ __forceinline__ bool vec_ok() const { return ((uintptr_t)out % 16) == 0 && zstride % 4 == 0; }
+    __device__ __forceinline__ void store4(int z, int m, int n, f32x4 v) const {
         typedef gemm::f32x4_u v4;
+        if (z != 0) {
+            *(f32x4*)(out + z * zstride + (int64_t)m * D + n) = v;
+            return;
+        }
         v += *(const v4*)(bias + n);
         const float lf0 = logf(1.0f + __fdiv_rn(f0[m], 700.0f));
         const float ph = __fdiv_rn(phase[m], 3.14159274101257324f);
@@ -412,24 +432,29 @@ struct EpiEmbed {
 // workgroups per tile that each stored a partial product), written back for the next residual and then normalised.
 struct LnPending {
     const float* part;   // [KS_SPLITS][rows][D] or null
-    const float* bias;
+    const float* bias;   // or null
     float* x_out;
+    int has_res;         // the kernel's x argument is the residual to add (else the row is the partial sum alone)
 };
 constexpr int KS_SPLITS = 4;
 constexpr int KS_MAX_ROWS = 256;   // up to 4 row tiles x 4 column tiles x 4 splits = 64 workgroups (344 rows measured slower than whole-K launches)
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int64_t rows,
-                                                        float* __restrict__ out, int split, LnPending pend = LnPending{nullptr, nullptr, nullptr}) {
+                                                        float* __restrict__ out, int split, LnPending pend = LnPending{nullptr, nullptr, nullptr, 0}) {
     // split != 0: the row is written as bf16 hi/lo groups (A operand of a split-bf16 GEMM): lanes 2j, 2j+1 own one group
     const int lane = threadIdx.x & 63;
     const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= rows) return;
-    f32x4 v = *(const f32x4*)(x + m * D + lane * 4);
+    f32x4 v;
     if (pend.part) {
-        f32x4 p0 = *(const f32x4*)(pend.part + m * D + lane * 4), p1 = *(const f32x4*)(pend.part + (rows + m) * D + lane * 4);
+        const f32x4 p0 = *(const f32x4*)(pend.part + m * D + lane * 4), p1 = *(const f32x4*)(pend.part + (rows + m) * D + lane * 4);
         const f32x4 p2 = *(const f32x4*)(pend.part + (2 * rows + m) * D + lane * 4), p3 = *(const f32x4*)(pend.part + (3 * rows + m) * D + lane * 4);
-        v = v + (((p0 + p1) + (p2 + p3)) + *(const f32x4*)(pend.bias + lane * 4));
+        v = (p0 + p1) + (p2 + p3);
+        if (pend.bias) v = v + *(const f32x4*)(pend.bias + lane * 4);
+        if (pend.has_res) v = *(const f32x4*)(x + m * D + lane * 4) + v;
         *(f32x4*)(pend.x_out + m * D + lane * 4) = v;
+    } else {
+        v = *(const f32x4*)(x + m * D + lane * 4);
     }
     const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / D);
     f32x4 d;
@@ -1530,7 +1555,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         ksplit_on = (e && e[0] == '0') ? 0 : 1;
     }
     const bool ksplit = ksplit_on && !bf.l[0].pre && M <= KS_MAX_ROWS;
-    LnPending pending{nullptr, nullptr, nullptr};
+    LnPending pending{nullptr, nullptr, nullptr, 0};
     auto residual_gemm = [&](gemm::Args g, const float* x_res, float* x_dst, const float* bias) {
         // x_dst = x_res + A B^T + bias, now or (ksplit) when the next LayerNorm reads it
         if (ksplit && gemm::dma_ok(g) && g.K % (32 * KS_SPLITS) == 0) {
@@ -1540,7 +1565,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
             g.sB_hi = kc;
             gemm::EpiStore e{bf.kpart, D, nullptr, 1, M * D, 0};
             gemm::dma_go<64, 64, gemm::EpiStore, 4, 4>(st, g, KS_SPLITS, e);
-            pending = LnPending{bf.kpart, bias, x_dst};
+            pending = LnPending{bf.kpart, bias, x_dst, 1};
             return x_res;   // the LayerNorm reads the residual from here
         }
         gemm::EpiResidual e{x_dst, x_res, D, bias};
@@ -1587,6 +1612,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
             g.A_split = a_is_split;
         }
     };
+    bool conv_split = false;
     // ---- prenet: conv k3 -> GroupNorm(4) -> LeakyReLU -> conv k3 ----
     {
         gemm::Args g = gemm::make(in.units, w.n_unit, bf.w1, 3 * w.n_unit, iM, D, 3 * w.n_unit);
@@ -1595,12 +1621,25 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         g.Fr = (int)Fr;
         g.Cin = w.n_unit;
         g.zeros = zero_page;
-        gemm::EpiStore e{bf.t1, D, w.prenet_conv1_b, 1, 0, 0};
-        PROF(PF_U2C_GEMM_CONV3, 2.0 * M * D * 3 * w.n_unit, 4.0 * M * (w.n_unit + D),
-             (gemm::launch<true, true, gemm::A_CONV3>(st, g, 1, e)));
+        // (small batches: the k = 3 Cin range of the two prenet convolutions is cut over KS_SPLITS workgroups per tile as
+        // well; conv1's partial products are summed by the GroupNorm statistics pass, conv2's by the first LayerNorm)
+        conv_split = ksplit && gemm::dma_ok(g) && g.K % (32 * KS_SPLITS) == 0 && w.n_unit % 32 == 0 && (3 * D) % (32 * KS_SPLITS) == 0 &&
+                     w.n_unit + 32 <= DDSP_ZERO_FLOATS;
+        if (conv_split) {
+            g.K /= KS_SPLITS;
+            g.kz = g.K;
+            gemm::EpiStore e{bf.kpart, D, nullptr, 1, M * D, 0};
+            PROF(PF_U2C_GEMM_CONV3, 2.0 * M * D * 3 * w.n_unit, 4.0 * M * (w.n_unit + D),
+                 (gemm::dma_go<64, 64, gemm::EpiStore, 4, 4, gemm::A_CONV3>(st, g, KS_SPLITS, e)));
+        } else {
+            gemm::EpiStore e{bf.t1, D, w.prenet_conv1_b, 1, 0, 0};
+            PROF(PF_U2C_GEMM_CONV3, 2.0 * M * D * 3 * w.n_unit, 4.0 * M * (w.n_unit + D),
+                 (gemm::launch<true, true, gemm::A_CONV3>(st, g, 1, e)));
+        }
     }
     PROF(PF_U2C_ROWWISE, 0, 4.0 * M * D,
-         hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(4, (unsigned)B), dim3(64 * GN_LANES), 0, st, bf.t1, (int)Fr, bf.gst));
+         hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(4, (unsigned)B), dim3(64 * GN_LANES), 0, st, bf.t1, (int)Fr, bf.gst,
+                            conv_split ? bf.kpart : nullptr, w.prenet_conv1_b, M));
     PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
          hipLaunchKernelGGL(groupnorm_lrelu_kernel, dim3(grid_for(M * (D / 4))), dim3(256), 0, st, bf.t1, bf.gst,
                             w.prenet_gn_w, w.prenet_gn_b, M, (int)Fr, bf.t2, asplit));
@@ -1613,8 +1652,17 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         g.Cin = D;
         g.zeros = zero_page;
         // the side embeddings (f0, phase, volume, speaker) are added in this GEMM's epilogue
-        EpiEmbed e{x, w.prenet_conv2_b, in.f0, in.phase, in.volume, w, in.spk_id, in.n_spk_id, in.mix, (int)Fr, dev_err};
-        PROF(PF_U2C_GEMM_CONV3, 2.0 * M * D * 3 * D, 8.0 * M * D, (gemm::launch<true, true, gemm::A_CONV3>(st, g, 1, e)));
+        if (conv_split) {
+            g.K /= KS_SPLITS;
+            g.kz = g.K;
+            EpiEmbed e{bf.kpart, w.prenet_conv2_b, in.f0, in.phase, in.volume, w, in.spk_id, in.n_spk_id, in.mix, (int)Fr, dev_err, M * D};
+            PROF(PF_U2C_GEMM_CONV3, 2.0 * M * D * 3 * D, 8.0 * M * D,
+                 (gemm::dma_go<64, 64, EpiEmbed, 4, 4, gemm::A_CONV3>(st, g, KS_SPLITS, e)));
+            pending = LnPending{bf.kpart, nullptr, x, 0};   // layer 0's LayerNorm sums the four partial products into x
+        } else {
+            EpiEmbed e{x, w.prenet_conv2_b, in.f0, in.phase, in.volume, w, in.spk_id, in.n_spk_id, in.mix, (int)Fr, dev_err, 0};
+            PROF(PF_U2C_GEMM_CONV3, 2.0 * M * D * 3 * D, 8.0 * M * D, (gemm::launch<true, true, gemm::A_CONV3>(st, g, 1, e)));
+        }
     }
     DDSP_LAUNCH_CHECK(ctx);
 
@@ -1626,7 +1674,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         // -- x_mid = x_in + to_out(linear_attention(LN(x_in)))
         PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
              hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, ln_src ? ln_src : b.x_in, L.norm_w, L.norm_b, M, b.y, asplit, pending));
-        pending = LnPending{nullptr, nullptr, nullptr};
+        pending = LnPending{nullptr, nullptr, nullptr, 0};
         {
             gemm::Args g = gemm::make(b.y, D, bf.wqkv + (size_t)l * 3 * INNER * D, D, iM, 3 * INNER, D);
             set_b(g, bf.wqkv + (size_t)l * 3 * INNER * D, asplit);
@@ -1713,7 +1761,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         // -- x_out = x_mid + conv_module(x_mid)
         PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
              hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, ln_src, L.cm_ln_w, L.cm_ln_b, M, b.y2, asplit, pending));
-        pending = LnPending{nullptr, nullptr, nullptr};
+        pending = LnPending{nullptr, nullptr, nullptr, 0};
         if (fuse_glu) {
             gemm::Args g = gemm::make(b.y2, D, bf.wglu + (size_t)l * 2 * INNER * D, D, iM, 2 * INNER, D);
             set_b(g, bf.wglu + (size_t)l * 2 * INNER * D, asplit);
