@@ -62,7 +62,10 @@ def test_unit2ctrl_large_batch_fused_glu_matches_oracle(dev, lib_path):
     assert (small - got[:2]).abs().max() < 2e-5
 
 
-@pytest.mark.parametrize("B,Fr", [(2, 12), (3, 172), (1, 87)])
+# (1, 87), (2, 12), (2, 128) and (1, 250): at most 256 rows - the residual GEMMs and the prenet convolutions run as K-split
+# launches whose partial products the following LayerNorm / GroupNorm pass sums (256 rows exactly, and a ragged last tile);
+# (3, 172) and (1, 257): just above, whole-K launches
+@pytest.mark.parametrize("B,Fr", [(2, 12), (3, 172), (1, 87), (2, 128), (1, 250), (1, 257)])
 @pytest.mark.parametrize("spk_mode", ["per_row", "broadcast", "mix"])
 def test_unit2ctrl_matches_oracle(dev, lib_path, B, Fr, spk_mode):
     model, cfg = synthetic.build_model("CombSub", seed=99)
