@@ -104,8 +104,11 @@ __global__ void __launch_bounds__(64 * (KG + KS_WAVES), 3) performer_kv_bf16_ker
     if (wave >= KG) {
         // ---- the staging waves: convert frame tile ft + 1 into the other LDS stage while waves 0..8 multiply tile ft ----
         // 512 tasks per tile in 8 rounds of 64 (one per lane); staging wave ws takes rounds ws, ws + 3, ws + 6:
-        //   rounds 0..3  k chunk: frame fi = 8 r + (lane >> 3), channels 8 c8 .. 8 c8 + 7, c8 = lane & 7 (two 16-byte loads)
-        //                -> three pieces, one 16-byte LDS write each; |k|^2 of a frame = 8 neighbouring lanes;
+        //   rounds 0..3  k chunk: frame fi = 8 r + (lane & 7), channels 8 c8 .. 8 c8 + 7, c8 = lane >> 3 (two 16-byte loads)
+        //                -> three pieces, one 16-byte LDS write each; |k|^2 of a frame = the 8 lanes 8 apart.  (The 8 lanes of
+        //                a write group hold 8 consecutive frames = 8 consecutive 16-byte slots; with c8 = lane & 7 they held
+        //                the 8 chunks of ONE frame, whose slots lie 512 bytes apart - the same banks: 39 % of this kernel's
+        //                LDS cycles were conflicts, r02_e_pmc_sq_synth.txt);
         //   rounds 4..7  v chunk: channel ch = lane, frame octet o = r - 4 = (step, half): the 8 frames of its slots (eight
         //                4-byte loads, each one 256-byte row segment across the wave) -> two pieces, already in slot order.
         const int ws = wave - KG;
@@ -120,8 +123,8 @@ __global__ void __launch_bounds__(64 * (KG + KS_WAVES), 3) performer_kv_bf16_ker
                 return;
             }
             if (r < 4) {
-                const int fi = 8 * r + (lane >> 3), f = 32 * ft + fi;
-                const float* src = kb + (int64_t)(f < Fr ? f : Fr - 1) * INNER + 8 * (lane & 7);
+                const int fi = 8 * r + (lane & 7), f = 32 * ft + fi;
+                const float* src = kb + (int64_t)(f < Fr ? f : Fr - 1) * INNER + 8 * (lane >> 3);
                 const f32x4_t a0 = *(const f32x4_t*)src, a1 = *(const f32x4_t*)(src + 4);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[e] = f < Fr ? (e < 4 ? a0[e & 3] : a1[e & 3]) : 0.f;
@@ -142,7 +145,7 @@ __global__ void __launch_bounds__(64 * (KG + KS_WAVES), 3) performer_kv_bf16_ker
             }
             uint4* st = lds + (ft & 1) * K_STAGE;
             if (r < 4) {
-                const int fi = 8 * r + (lane >> 3), c8 = lane & 7;
+                const int fi = 8 * r + (lane & 7), c8 = lane >> 3;
                 u32x4 pc[3];
                 split<3>(x, pc);
 #pragma unroll
@@ -151,9 +154,9 @@ __global__ void __launch_bounds__(64 * (KG + KS_WAVES), 3) performer_kv_bf16_ker
                 float ss = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ss = fmaf(x[e], x[e], ss);
-                ss += __shfl_xor(ss, 1, 64);
-                ss += __shfl_xor(ss, 2, 64);
-                ss += __shfl_xor(ss, 4, 64);
+                ss += __shfl_xor(ss, 8, 64);
+                ss += __shfl_xor(ss, 16, 64);
+                ss += __shfl_xor(ss, 32, 64);
                 if (c8 == 0) {
                     const float d[8] = {NEG_HALF * ss, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     u32x4 dp[3];
