@@ -222,3 +222,33 @@ def test_noise_conv_building_block(ctx, dev):
         got = ctx.nsf_noise_conv(src.to(dev), w.to(dev), b.to(dev), K, s, pad, T_out)
         assert got.shape == (T_out, C)
         assert float((got.cpu().double() - want).abs().max()) < 2e-5, (C, K, s)
+
+
+def _unsplit(t):
+    """Decode the split operand layout (groups of 8 floats = 8 bf16 high parts | 8 bf16 remainders) back to fp32."""
+    b = t.contiguous().view(torch.bfloat16).reshape(*t.shape[:-1], t.shape[-1] // 8, 16)
+    return (b[..., :8].float() + b[..., 8:].float()).reshape(t.shape)
+
+
+def test_conv1d_split_operands_and_large_tiles(ctx, dev):
+    """The generator's wide stages at sizes where the convolution picks its larger tiles (128x128 for 128-channel multiples
+    from 256 workgroups, 128x64 from 512), with the operands as the generator passes them: input and weight in the split
+    layout, raw output in fp32, activated output in the split layout (decoded here)."""
+    import hipddsp
+    g = torch.Generator().manual_seed(12)
+    for (T, C, k, d) in [(40000, 128, 7, 3), (70000, 64, 3, 1), (3000, 256, 11, 5), (33000, 128, 3, 5)]:
+        x = torch.randn(T, C, generator=g)
+        w = torch.randn(C, C, k, generator=g) / np.sqrt(C * k)
+        b = torch.randn(C, generator=g)
+        r = torch.randn(T, C, generator=g)
+        wp = w.permute(0, 2, 1).reshape(C, -1).contiguous()
+        xs, ws = hipddsp.presplit(x), hipddsp.presplit(wp)
+        # what the kernel multiplies: the two-piece values of x and w (their fp32 originals differ by ~4e-6 relative)
+        want = torch.nn.functional.conv1d(_unsplit(xs).double().t()[None], _unsplit(ws).reshape(C, k, C).permute(0, 2, 1).double(),
+                                          b.double(), dilation=d, padding=(k * d - d) // 2)[0].t() + r.double()
+        out, act = ctx.conv1d(xs.to(dev), wp.to(dev), b.to(dev), k, d, 1.0, residual=r.to(dev), act_slope=0.1, w_split=ws.to(dev),
+                              x_split=True, act_split=True)
+        assert float((out.cpu().double() - want).abs().max()) < 3e-5, (T, C, k, d)
+        act_want = torch.nn.functional.leaky_relu(out.cpu(), 0.1)
+        assert float((_unsplit(act.cpu()) - act_want).abs().max()) < 2e-5 * float(act_want.abs().max())
+        assert torch.equal(act.cpu(), hipddsp.presplit(act_want))          # the same bits as the host-side conversion
