@@ -775,6 +775,18 @@ inline void launch_tile(hipStream_t st, const Args& g, int batch, const Epi& epi
     hipLaunchKernelGGL((kernel<BM, BN, A_KC, B_KC, A_MODE, Epi, NW>), grid, dim3(64 * NW), 0, st, g, epi);
 }
 
+// workgroups from which the 128x128 tile is preferred to 128x64 (DDSP_GEMM_T128_MIN: measurement aid; 256 instead of 512:
+// training step 6.40 -> 6.51 ms, the B = 47 forward 1.05 -> 1.14 ms - unlike the enhancer's dilated convolutions, which gain
+// from 128x128 tiles from 256 workgroups on, nsf.hip)
+inline int64_t t128_min() {
+    static int64_t v = -1;
+    if (v < 0) {
+        const char* e = getenv("DDSP_GEMM_T128_MIN");
+        v = e ? atoll(e) : 512;
+    }
+    return v;
+}
+
 // Tile choice (measured on MI355X, tools/gemm_ab.py, fp32 TFLOP/s at M = 11008):
 //   K%32==0, row-major A, [N][K] B  -> persistent LDS-DMA kernel, 128x64 tiles, 8 waves  (69-83 at K=256, N=512..1536)
 //   otherwise                        -> register-staged kernel: 128x64 / 8 waves when the grid fills the chip,
@@ -828,7 +840,7 @@ inline void launch(hipStream_t st, const Args& g, int batch, const Epi& epi) {
             // (tools/gemm_ab.py, M=11008: N=256 K=512 35.3 vs 38.8 us, K=768 49.2 vs 54.8 us)
             if (g.N <= 256)
                 dma_go<64, 64, Epi, 3, 4>(st, g, batch, epi);
-            else if (blocks(128, 128) >= 512) {
+            else if (blocks(128, 128) >= t128_min()) {
                 // 512 resident workgroups walk the tiles in rounds.  When the last round holds only a few tiles (QKV at
                 // the bench shape: 1032 = 2 * 512 + 8) those run alone on their CUs for a whole tile time; they are
                 // cut out of this launch and run as 64x64 tiles on 4 waves instead (4 small workgroups per tile).
