@@ -567,15 +567,21 @@ extern "C" int ddsp_conv1d(ddsp_ctx* ctx, void* stream, const float* x, const fl
             // tile choice (860 frames, generator 5.86 / 5.53 / 5.19 ms with 0 / 1 / 2): 0 = 64x64 on 4 waves everywhere,
             // 1 = 128x64 on 8 waves where that still gives 512 workgroups, 2 = also 128x128 for 128-channel multiples from 256
             // workgroups (the 128-channel stage: 1.45 -> 0.99 ms, one column tile instead of two re-reading the input)
+            // 3 = also 64x128 on 4 waves for the 128-channel multiples that fill neither (the 256-channel stage at 6880 rows and
+            // the transposed convolutions: 5.17 -> 4.98 ms; 4 = 128x128 there instead: 5.18)
             const char* ev = getenv("DDSP_CONV_TILE");
-            conv_tile = ev ? atoi(ev) : 2;
+            conv_tile = ev ? atoi(ev) : 3;
         }
         if (Cout > 256 && blocks(128, 128) >= 512)
             gemm::dma_go<128, 128, EpiAddBias, 2, 8, gemm::A_CONVK>(st, g, 1, e);
-        else if (conv_tile == 2 && Cout % 128 == 0 && blocks(128, 128) >= 256)
+        else if (conv_tile >= 2 && Cout % 128 == 0 && blocks(128, 128) >= 256)
             gemm::dma_go<128, 128, EpiAddBias, 2, 8, gemm::A_CONVK>(st, g, 1, e);
         else if (conv_tile >= 1 && blocks(128, 64) >= 512)
             gemm::dma_go<128, 64, EpiAddBias, 3, 8, gemm::A_CONVK>(st, g, 1, e);
+        else if (conv_tile == 3 && Cout % 128 == 0 && blocks(64, 128) >= 128)
+            gemm::dma_go<64, 128, EpiAddBias, 3, 4, gemm::A_CONVK>(st, g, 1, e);
+        else if (conv_tile == 4 && Cout % 128 == 0 && blocks(128, 128) >= 64)
+            gemm::dma_go<128, 128, EpiAddBias, 2, 8, gemm::A_CONVK>(st, g, 1, e);
         else
             gemm::dma_go<64, 64, EpiAddBias, 3, 4, gemm::A_CONVK>(st, g, 1, e);
     } else if (blocks(128, 64) >= 512)
