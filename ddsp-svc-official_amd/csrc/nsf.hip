@@ -381,14 +381,15 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
     const f32x2v rem = (f32x2v){a, b} - (f32x2v){__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(rem, bf16x2v));
 }
-__global__ void __launch_bounds__(256) conv_small32_bf16_kernel(ConvSmallArgs g) {
+__global__ void __launch_bounds__(512) conv_small32_bf16_kernel(ConvSmallArgs g) {   // 4 .. 8 waves: as many windows as fit the LDS beside the weight
     constexpr int C = 32;
     extern __shared__ uint32_t ldsu[];
     const int halo = (g.ktaps - 1) / 2 * g.dil, rows = CS_TW + 2 * halo;
     uint32_t* const wl = ldsu;                                          // [tap][co] row images of the 32 ci
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* const win = ldsu + g.ktaps * C * CB_PITCH + wave * rows * CB_PITCH;
-    for (int i4 = threadIdx.x; i4 < g.ktaps * C * C / 4; i4 += 256) {   // four consecutive ci of one (co, tap)
+    const int nwaves = blockDim.x >> 6;
+    for (int i4 = threadIdx.x; i4 < g.ktaps * C * C / 4; i4 += blockDim.x) {   // four consecutive ci of one (co, tap)
         const int e = i4 * 4, co = e / (g.ktaps * C), r = e % (g.ktaps * C), tap = r / C, ci = r % C;
         const f32x4 v = *(const f32x4*)(g.w + e);
         uint32_t h0, l0, h1, l1;
@@ -433,7 +434,7 @@ __global__ void __launch_bounds__(256) conv_small32_bf16_kernel(ConvSmallArgs g)
             }
         }
     };
-    const int64_t first = (int64_t)blockIdx.x * 4 + wave, step = (int64_t)gridDim.x * 4;
+    const int64_t first = (int64_t)blockIdx.x * nwaves + wave, step = (int64_t)gridDim.x * nwaves;
     if (first < nchunks) {
         load_window(first * CS_TW);
         store_window();
@@ -489,14 +490,18 @@ __global__ void __launch_bounds__(256) conv_small32_bf16_kernel(ConvSmallArgs g)
 
 static int launch_conv_small32_bf16(ddsp_ctx* ctx, hipStream_t st, const ConvSmallArgs& g) {
     const int halo = (g.ktaps - 1) / 2 * g.dil, rows = CS_TW + 2 * halo;
-    const size_t lds = ((size_t)g.ktaps * 32 + 4 * (size_t)rows) * CB_PITCH * sizeof(uint32_t);
-    if (lds > 160 * 1024) return ddsp_fail(ctx, DDSP_ERR_ARG, "ddsp_conv1d", "window too long for the LDS");
+    const size_t w_bytes = (size_t)g.ktaps * 32 * CB_PITCH * sizeof(uint32_t), win_bytes = (size_t)rows * CB_PITCH * sizeof(uint32_t);
+    // one wave per SIMD waits out every LDS fragment read (the same convolution: 54 us with two workgroups per CU, 78 us with
+    // one): as many wavefronts (windows) per workgroup as fit beside the weight image, 8 at most
+    int nw = (int)((160 * 1024 - w_bytes) / win_bytes);
+    nw = nw > 8 ? 8 : nw;
+    if (nw < 1) return ddsp_fail(ctx, DDSP_ERR_ARG, "ddsp_conv1d", "window too long for the LDS");
+    const size_t lds = w_bytes + nw * win_bytes;
     DDSP_ONCE_PER_DEVICE(ctx, DDSP_HIP(ctx, hipFuncSetAttribute((const void*)conv_small32_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
     const int64_t nchunks = (g.T + CS_TW - 1) / CS_TW;
-    int64_t blocks = (nchunks + 3) / 4;
-    const int64_t cap = 256 * (lds > 80 * 1024 ? 1 : lds > 53 * 1024 ? 2 : 3);
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(conv_small32_bf16_kernel, dim3((unsigned)blocks), dim3(256), lds, st, g);
+    int64_t blocks = (nchunks + nw - 1) / nw;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(conv_small32_bf16_kernel, dim3((unsigned)blocks), dim3(64 * nw), lds, st, g);
     return DDSP_OK;
 }
 
