@@ -381,10 +381,11 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
     const f32x2v rem = (f32x2v){a, b} - (f32x2v){__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(rem, bf16x2v));
 }
+template <int NT>   // frame tiles of 32 per window: 2, or 1 when the halo would otherwise leave fewer than 8 windows in the LDS
 __global__ void __launch_bounds__(512) conv_small32_bf16_kernel(ConvSmallArgs g) {   // 4 .. 8 waves: as many windows as fit the LDS beside the weight
-    constexpr int C = 32;
+    constexpr int C = 32, TWK = 32 * NT;
     extern __shared__ uint32_t ldsu[];
-    const int halo = (g.ktaps - 1) / 2 * g.dil, rows = CS_TW + 2 * halo;
+    const int halo = (g.ktaps - 1) / 2 * g.dil, rows = TWK + 2 * halo;
     uint32_t* const wl = ldsu;                                          // [tap][co] row images of the 32 ci
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* const win = ldsu + g.ktaps * C * CB_PITCH + wave * rows * CB_PITCH;
@@ -402,8 +403,8 @@ __global__ void __launch_bounds__(512) conv_small32_bf16_kernel(ConvSmallArgs g)
         p[17] = l1;
     }
     __syncthreads();
-    const int64_t nchunks = (g.T + CS_TW - 1) / CS_TW;
-    constexpr int NV = ((CS_TW + 2 * CS_MAX_HALO) * C / 4 + 63) / 64;
+    const int64_t nchunks = (g.T + TWK - 1) / TWK;
+    constexpr int NV = ((TWK + 2 * CS_MAX_HALO) * C / 4 + 63) / 64;
     const int nvec = rows * C / 4;
     f32x4 pre[NV];
     auto load_window = [&](int64_t t0) {
@@ -436,18 +437,18 @@ __global__ void __launch_bounds__(512) conv_small32_bf16_kernel(ConvSmallArgs g)
     };
     const int64_t first = (int64_t)blockIdx.x * nwaves + wave, step = (int64_t)gridDim.x * nwaves;
     if (first < nchunks) {
-        load_window(first * CS_TW);
+        load_window(first * TWK);
         store_window();
     }
     const int li = lane & 31, lh = lane >> 5;
     for (int64_t chunk = first; chunk < nchunks; chunk += step) {
-        const int64_t t0 = chunk * CS_TW;
+        const int64_t t0 = chunk * TWK;
         const bool more = chunk + step < nchunks;
-        if (more) load_window((chunk + step) * CS_TW);
+        if (more) load_window((chunk + step) * TWK);
         __builtin_amdgcn_wave_barrier();
-        f32x16 acc[2];
+        f32x16 acc[NT];
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
+        for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
         for (int tap = 0; tap < g.ktaps; ++tap) {
@@ -459,7 +460,7 @@ __global__ void __launch_bounds__(512) conv_small32_bf16_kernel(ConvSmallArgs g)
                 const nsf_bf16x8 bh = __builtin_bit_cast(nsf_bf16x8, *(const ddsp_u32x4*)(wr + 8 * s));
                 const nsf_bf16x8 bl = __builtin_bit_cast(nsf_bf16x8, *(const ddsp_u32x4*)(wr + 8 * s + 16));
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
+                for (int tt = 0; tt < NT; ++tt) {
                     const nsf_bf16x8 ah = __builtin_bit_cast(nsf_bf16x8, *(const ddsp_u32x4*)(xr + tt * 32 * CB_PITCH + 8 * s));
                     const nsf_bf16x8 al = __builtin_bit_cast(nsf_bf16x8, *(const ddsp_u32x4*)(xr + tt * 32 * CB_PITCH + 8 * s + 16));
                     acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[tt], 0, 0, 0);
@@ -471,7 +472,7 @@ __global__ void __launch_bounds__(512) conv_small32_bf16_kernel(ConvSmallArgs g)
         // D[(r & 3) + 8*(r >> 2) + 4*(l >> 5)][l & 31]: row = frame (the A operand's row), column = co
         const float bc = g.bias ? g.bias[li] : 0.f;
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
+        for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t t = t0 + tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -489,19 +490,28 @@ __global__ void __launch_bounds__(512) conv_small32_bf16_kernel(ConvSmallArgs g)
 }
 
 static int launch_conv_small32_bf16(ddsp_ctx* ctx, hipStream_t st, const ConvSmallArgs& g) {
-    const int halo = (g.ktaps - 1) / 2 * g.dil, rows = CS_TW + 2 * halo;
-    const size_t w_bytes = (size_t)g.ktaps * 32 * CB_PITCH * sizeof(uint32_t), win_bytes = (size_t)rows * CB_PITCH * sizeof(uint32_t);
+    const int halo = (g.ktaps - 1) / 2 * g.dil;
+    const size_t w_bytes = (size_t)g.ktaps * 32 * CB_PITCH * sizeof(uint32_t);
+    // two frame tiles per window unless that leaves fewer than 8 windows: then one (11 taps at dilation 5: 6 x 114 rows -> 8 x 82)
+    int nt = 2;
+    if ((160 * 1024 - w_bytes) / ((size_t)(64 + 2 * halo) * CB_PITCH * sizeof(uint32_t)) < 8) nt = 1;
+    const int twk = 32 * nt, rows = twk + 2 * halo;
+    const size_t win_bytes = (size_t)rows * CB_PITCH * sizeof(uint32_t);
     // one wave per SIMD waits out every LDS fragment read (the same convolution: 54 us with two workgroups per CU, 78 us with
     // one): as many wavefronts (windows) per workgroup as fit beside the weight image, 8 at most
     int nw = (int)((160 * 1024 - w_bytes) / win_bytes);
     nw = nw > 8 ? 8 : nw;
     if (nw < 1) return ddsp_fail(ctx, DDSP_ERR_ARG, "ddsp_conv1d", "window too long for the LDS");
     const size_t lds = w_bytes + nw * win_bytes;
-    DDSP_ONCE_PER_DEVICE(ctx, DDSP_HIP(ctx, hipFuncSetAttribute((const void*)conv_small32_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
-    const int64_t nchunks = (g.T + CS_TW - 1) / CS_TW;
+    DDSP_ONCE_PER_DEVICE(ctx, DDSP_HIP(ctx, hipFuncSetAttribute((const void*)conv_small32_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                         DDSP_HIP(ctx, hipFuncSetAttribute((const void*)conv_small32_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+    const int64_t nchunks = (g.T + twk - 1) / twk;
     int64_t blocks = (nchunks + nw - 1) / nw;
     if (blocks > 256) blocks = 256;
-    hipLaunchKernelGGL(conv_small32_bf16_kernel, dim3((unsigned)blocks), dim3(64 * nw), lds, st, g);
+    if (nt == 2)
+        hipLaunchKernelGGL(conv_small32_bf16_kernel<2>, dim3((unsigned)blocks), dim3(64 * nw), lds, st, g);
+    else
+        hipLaunchKernelGGL(conv_small32_bf16_kernel<1>, dim3((unsigned)blocks), dim3(64 * nw), lds, st, g);
     return DDSP_OK;
 }
 
