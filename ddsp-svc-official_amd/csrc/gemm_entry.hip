@@ -39,6 +39,9 @@ extern "C" int ddsp_gemm_f32(ddsp_ctx* ctx, void* stream, const float* A, int64_
         else if (tile == 53) gemm::launch_dma<64, 64, gemm::EpiStore, 3, 0, 4, gemm::A_PLAIN, 8>(st, g, 1, e);
         else if (tile == 54) gemm::launch_dma<128, 64, gemm::EpiStore, 3, 0, 8, gemm::A_PLAIN, 8>(st, g, 1, e);
         else if (tile == 55) gemm::launch_dma<128, 128, gemm::EpiStore, 3, 0, 8, gemm::A_PLAIN, 8>(st, g, 1, e);
+        else if (tile == 58) gemm::launch_dma<128, 128, gemm::EpiStore, 2, 4, 8, gemm::A_PLAIN, 8>(st, g, 1, e);   // 50 without epilogue stores
+        else if (tile == 59) gemm::launch_dma<128, 128, gemm::EpiStore, 2, 1, 8, gemm::A_PLAIN, 8>(st, g, 1, e);   // 50 without MFMAs
+        else if (tile == 60) gemm::launch_dma<128, 128, gemm::EpiStore, 2, 2, 8, gemm::A_PLAIN, 8>(st, g, 1, e);   // 50 without DMA
         else if (tile == 56) gemm::launch_dma<64, 128, gemm::EpiStore, 3, 0, 4, gemm::A_PLAIN, 8>(st, g, 1, e);
         else if (tile == 57) gemm::launch_dma<64, 128, gemm::EpiStore, 2, 0, 4, gemm::A_PLAIN, 8>(st, g, 1, e);
         else if (tile == 40) gemm::launch_dma<128, 128, gemm::EpiStore, 2, 0, 4, gemm::A_PLAIN, 3>(st, g, 1, e);  // split-bf16 x3, 128x128 on 4 waves (64x64 per wave)

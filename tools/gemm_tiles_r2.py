@@ -12,7 +12,7 @@ for (M, N, K) in [(11008, 1536, 256), (11008, 1024, 256), (11008, 256, 512), (11
     ref = A.double() @ B.double().t()
     res = {}
     A = A.abs() * 0.01; B = B.abs() * 0.01        # (as bf16 bit patterns: small finite numbers)
-    for tile in (50, 51, 52, 53, 54, 55, 56, 57):
+    for tile in (50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60):
         C = ctx.gemm(A, B, tile=tile)
         res[tile] = []
     for rnd in range(5):
