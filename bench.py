@@ -40,19 +40,38 @@ PEAK_MFMA_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 
 #  kernels, fp32 157.3 TFLOP/s otherwise).  A split-bf16 kernel forms every fp32 product from 3 bf16 MFMAs (hi*hi + hi*lo +
 #  lo*hi, fp32 accumulation), i.e. ISSUES three times its algorithmic FLOP: that utilisation figure is `mfma_issue_frac`.
 FAMILIES_TIMED = ("ltv_fir", "u2c_gemm_linear", "u2c_gemm_ctx", "u2c_gemm_attnout")
-SPLIT_FAMILIES = ("ltv_fir", "u2c_gemm_linear")     # families whose products follow the context's math mode
-KERNEL_LABEL = {
-    "u2c_gemm_ctx": "performer_kv_kernel (fused key feature map + k'^T v context, fp32 MFMA 16x16x4, one wavefront per "
-                    "(utterance, head, feature tile); three launches per step)",
-    "u2c_gemm_attnout": "performer_q_kernel (fused query feature map + q' ctx / (q' ks), fp32 MFMA 16x16x4, one wavefront "
-                        "per (utterance, head, frame tile); three launches per step)",
-    "ltv_fir": "ltv_fir_bf16_kernel (frame-varying FIR as Toeplitz-block products, split-bf16 = 3 bf16 MFMA 16x16x32 per "
-               "fp32 product, operands split while staged into the LDS; three launches per step: all-pass 510 taps, "
-               "source 1022 taps, noise 510 taps)",
-    "u2c_gemm_linear": "gemm::kernel_dma (persistent LDS-DMA GEMM, split-bf16 products = 3 bf16 MFMA 32x32x16 per fp32 "
-                       "product): Linear / 1x1-conv layers of unit2ctrl - 128x128 tiles on 8 waves for QKV (its last 8 "
-                       "tiles as 64x64 tiles in a second kernel), pw1+GLU and the head, 64x64 tiles on 4 waves for the "
-                       "N=256 layers",
+# Families whose products follow the context's math mode (ddsp_ctx_set_math): with the default (split-bf16) they issue on the
+# bf16 matrix pipe, every fp32 product formed from ISSUE_MULT bf16 MFMAs; with FP32 (the second leg) on the fp32 matrix pipe.
+# The attention kernels are among them at this batch (B * 8 heads >= 256: performer_attn_bf16.hip; below that, and in the FP32
+# leg, the fp32 kernels of performer_attn.hip run): their feature projections enter an exponential and are formed from three
+# bf16 pieces per operand = 6 MFMAs per fp32 product, their context products from two pieces = 3 MFMAs - half the FLOP each.
+SPLIT_FAMILIES = ("ltv_fir", "u2c_gemm_linear", "u2c_gemm_ctx", "u2c_gemm_attnout")
+ISSUE_MULT = {"ltv_fir": 3.0, "u2c_gemm_linear": 3.0, "u2c_gemm_ctx": 4.5, "u2c_gemm_attnout": 4.5}
+SPLIT_ARITH = {"ltv_fir": "split-bf16: 3 bf16 MFMAs per fp32 product, fp32 accumulation",
+               "u2c_gemm_linear": "split-bf16: 3 bf16 MFMAs per fp32 product, fp32 accumulation",
+               "u2c_gemm_ctx": "split-bf16, fp32 accumulation: k P^T from three bf16 pieces per operand (6 MFMAs per fp32 "
+                               "product, it enters an exponential), k'^T v from two (3 MFMAs): 4.5 on average",
+               "u2c_gemm_attnout": "split-bf16, fp32 accumulation: q P^T from three bf16 pieces per operand (6 MFMAs per fp32 "
+                                   "product), q' ctx from two (3 MFMAs): 4.5 on average"}
+KERNEL_LABEL = {   # (default leg: split-bf16 products, FP32 leg)
+    "u2c_gemm_ctx": ("performer_kv_bf16_kernel (one workgroup per (utterance, head): key feature map + k'^T v context, "
+                     "v_mfma_f32_32x32x16_bf16, operands converted once per workgroup into LDS images in MFMA order; three "
+                     "launches per step)",
+                     "performer_kv_kernel (fused key feature map + k'^T v context, fp32 MFMA 16x16x4, one wavefront per "
+                     "(utterance, head, feature tile); three launches per step)"),
+    "u2c_gemm_attnout": ("performer_q_bf16_kernel (one workgroup per (utterance, head): query feature map + q' ctx / (q' ks), "
+                         "v_mfma_f32_32x32x16_bf16, ctx pieces streamed global -> LDS; three launches per step)",
+                         "performer_q_kernel (fused query feature map + q' ctx / (q' ks), fp32 MFMA 16x16x4, one wavefront "
+                         "per (utterance, head, frame tile); three launches per step)"),
+    "ltv_fir": ("ltv_fir_bf16_march_kernel (frame-varying FIR as Toeplitz-block products, 3 bf16 MFMA 16x16x32 per fp32 "
+                "product, operands split while staged into the LDS; three launches per step: all-pass 510 taps, source 1022 "
+                "taps, noise 510 taps)",
+                "ltv_fir_kernel: the same launches with products on the fp32 matrix pipe (ddsp_ctx_set_math FP32)"),
+    "u2c_gemm_linear": ("gemm::kernel_dma (persistent LDS-DMA GEMM, 3 bf16 MFMA 32x32x16 per fp32 product, operands pre-split): "
+                        "Linear / 1x1-conv layers of unit2ctrl - 128x128 tiles on 8 waves for QKV and pw1+GLU, 64x64 tiles on 4 "
+                        "waves for the N=256 layers; the head on gemm::kernel_ws (loader / product waves, gemm_ws.h); 13 "
+                        "launches per step",
+                        "the same launches with products on the fp32 matrix pipe (ddsp_ctx_set_math FP32): gemm::kernel_dma"),
 }
 
 
@@ -97,9 +116,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="CombSub", choices=["CombSub", "Sins256", "CombSubFast"])
-    ap.add_argument("--mode", default="synth", choices=["synth", "train"],
+    ap.add_argument("--mode", default="synth", choices=["synth", "train", "realtime"],
                     help="synth (default, BASELINE configs[1]): forward only; train (configs[3]): one full training "
-                         "step per iteration, 32 clips per GPU, gradient all-reduce over RCCL")
+                         "step per iteration, 32 clips per GPU, gradient all-reduce over RCCL; realtime (configs[4]): one "
+                         "stream per GPU, one step = one 0.2 s block through realtime.StreamRenderer (replicas, no collective)")
     return ap.parse_args()
 
 
@@ -178,6 +198,76 @@ def parity_sample(model_cpu_sd, cfg, model, inp, inp_cpu, seed, ctx, dev):
     return out
 
 
+def realtime_mode(args, model, dev, dist, world, rank):
+    """BASELINE configs[4]: one real-time stream per GPU (replicas only): a step is ONE 0.2 s block through
+    `realtime.StreamRenderer` - sliding 44 100-sample window (87 frames), frame volume, model forward replayed from a HIP graph,
+    volume gate, SOLA splice - with synthetic analysis features.  Every block is timed on its own from an idle stream to its
+    last kernel (what the audio callback waits for); the line reports the mean and the p99 over the K blocks, the slowest
+    rank's figures, and `value` = streams x block samples / mean block time."""
+    import realtime
+    import synthetic
+    sr, block_time = SR, 0.2
+    r = realtime.StreamRenderer(model, sr, block_time, 0.04, dev, buffer_num=4, threshold_db=-60.0, spk_id=1, use_graph=True)
+    feats = [{k: v.to(dev) for k, v in synthetic.make_inputs(9000 + 17 * rank + i, 1, r.frames, with_noise=False).items()}
+             for i in range(8)]
+    g = torch.Generator(device=dev).manual_seed(11 + rank)
+    blocks = [0.2 * torch.randn(r.block, device=dev, generator=g) for _ in range(8)]
+
+    def one(i):
+        f = feats[i % 8]
+        return r.push_block(blocks[i % 8], units=f["units"], f0=f["f0"])
+
+    for i in range(args.warmup):
+        one(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    lat = []
+    t_all = time.perf_counter()
+    for i in range(args.steps):
+        t0 = time.perf_counter()
+        one(args.warmup + i)
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t0) * 1e3)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t_all
+    lat.sort()
+    mean, p99 = sum(lat) / len(lat), lat[min(len(lat) - 1, int(0.99 * len(lat)))]
+    # back-to-back blocks without the per-block host synchronisation: the device-side pace of the chain
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(args.steps):
+        one(i)
+    e1.record()
+    torch.cuda.synchronize()
+    pace = e0.elapsed_time(e1) / args.steps
+    stats = torch.tensor([dt, mean, p99, pace], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+    dt, mean, p99, pace = [float(v) for v in stats]
+    if rank == 0:
+        print(json.dumps({
+            "metric": "audio samples/sec @44.1kHz CombSub real-time streams (0.2 s blocks, SOLA splice, one stream per GPU)",
+            "value": world * r.block / (mean * 1e-3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": mean, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 storage and accumulation; at this batch (87 rows) the Linear / conv products are split-bf16x3 with "
+                     "pre-split weights, attention and FIR products f32",
+            "data": "synthetic",
+            "config": {"workload": f"CombSub 44.1 kHz real-time: one stream per GPU, {r.n_in}-sample sliding window "
+                                   f"({r.frames} frames), block {r.block}, cross-fade {r.splicer.xfade}, search {r.splicer.search}; "
+                                   "window -> volume -> model (HIP-graph replay) -> gate -> SOLA per block",
+                       "sharding": "replicas only (one stream per GPU, no collective)"},
+            "ms_per_block_mean": mean, "ms_per_block_p99": p99, "ms_per_block_back_to_back": pace,
+            "x_realtime_per_stream": 200.0 / mean,
+            "timed_region_s": dt,
+        }), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -215,6 +305,9 @@ def main():
     inp = {k: v.to(dev) for k, v in inp_cpu.items()}
     T = FRAMES * HOP
     ctx = hipddsp.context_for(dev)
+
+    if args.mode == "realtime":
+        return realtime_mode(args, model, dev, dist, world, rank)
 
     gather = sharding.AudioGather(world, B_PER_GPU, T, dev) if world > 1 else None
 
@@ -285,6 +378,34 @@ def main():
         dt32, timed32 = timed_leg(100_000)
         ctx.set_math(hipddsp.MATH_SPLIT_BF16)
 
+    # strong scaling (a FIXED 64-clip job, what a main.py / gui.py batch looks like): at N = 1 the per-GPU share of an 8-GPU
+    # run of that job - 8 clips - is timed with the same protocol (the one-GPU job itself is leg 1); at N > 1 the 64 clips are
+    # sharded over the ranks (64 / N each) and gathered like the weak-scaled leg
+    strong = None
+    if args.mode == "synth":
+        shard = 8 if world == 1 else max(1, B_PER_GPU // world)
+        sub = {k: v[:shard].contiguous() for k, v in inp.items()}
+        g2 = sharding.AudioGather(world, shard, T, dev) if world > 1 else None
+        keep_step, keep_gather = step, gather
+
+        def step(i):   # noqa: F811
+            with torch.no_grad():
+                sig, _, _ = model(sub["units"], sub["f0"], sub["volume"], sub["spk_id"], noise_seed=3000 + i)
+            if g2 is not None:
+                g2.submit(sig)
+            return sig
+        gather = g2
+        dts, _ = timed_leg(200_000)
+        step, gather = keep_step, keep_gather
+        strong = {"job": f"{B_PER_GPU if world > 1 else 64} clips x 2 s in total", "clips_per_gpu": shard,
+                  "ms_per_step": dts / args.steps * 1e3}
+        if world == 1:
+            strong["note"] = ("N = 1: the per-GPU work of an 8-GPU strong-scaled run (8 of the 64 clips); projected speed-up = "
+                              "ms_per_step of the 64-clip leg / this")
+            strong["projected_speedup_8_gpus"] = (dt / args.steps * 1e3) / strong["ms_per_step"]
+        else:
+            strong["value"] = world * shard * T * args.steps / dts
+
     total_samples = world * Bt * T * args.steps
     value = total_samples / dt
     out = {
@@ -293,8 +414,10 @@ def main():
                   f"audio samples/sec @44.1kHz {args.model} training step (fwd + RSS loss + bwd + AdamW)",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": ("f32 storage and accumulation; products of the GEMM/FIR contractions split-bf16x3 (hi*hi+hi*lo+lo*hi), "
-                  "attention and all other arithmetic f32; `value_fp32_mfma` is the all-f32 leg") if args.mode == "synth"
+        "dtype": ("f32 storage and accumulation; products of the GEMM / FIR contractions split-bf16x3 (hi*hi+hi*lo+lo*hi), of the "
+                  "attention split-bf16 from three pieces (6 products) for the feature projections and two (3 products) for "
+                  "the context sums; everything else f32; `value_fp32_mfma` is the leg with every product in f32"
+                  ) if args.mode == "synth"
         else "f32 storage and accumulation; forward, spectral loss, attention / FIR adjoints and optimizer in f32 products; "
              "weight and input gradients of the Linear / conv layers split-bf16x3 (hi*hi+hi*lo+lo*hi)",
         "data": "synthetic",
@@ -310,6 +433,8 @@ def main():
     if dt32 is not None:
         out["value_fp32_mfma"] = total_samples / dt32
         out["ms_per_step_fp32_mfma"] = dt32 / args.steps * 1e3
+    if strong is not None:
+        out["strong_scaling"] = strong
     # untimed breakdown pass: every kernel family bracketed by events (adds launch gaps, so not part of `value`)
     ctx.profile_begin()
     nb = 3
@@ -324,20 +449,18 @@ def main():
             d = timed[name]
             avg_ms = d["ms_total"] / d["launches"]
             alg = d["flops_total"] / d["launches"] / (avg_ms * 1e-3) / 1e12
-            r = {"kernel": KERNEL_LABEL[name], "bound": "mfma", "unit": "TFLOP/s",
+            on_bf16 = split and name in SPLIT_FAMILIES and (args.mode == "synth" or name == "ltv_fir")
+            r = {"kernel": KERNEL_LABEL[name][0 if on_bf16 else 1], "bound": "mfma", "unit": "TFLOP/s",
                  "traffic": measured_traffic(name, split), "avg_launch_ms": avg_ms, "launches": d["launches"],
                  "ms_per_step": d["ms_total"] / args.steps,
                  "algorithmic_bytes_per_launch": d["bytes_total"] / d["launches"],
                  "algorithmic_flops_per_launch": d["flops_total"] / d["launches"]}
-            if split and (name == "ltv_fir" or (name in SPLIT_FAMILIES and args.mode == "synth")):
-                r.update({"arithmetic": "split-bf16: 3 bf16 MFMAs per fp32 product, fp32 accumulation",
-                          "achieved": alg, "peak": PEAK_MFMA_BF16_TFLOPS, "frac": alg / PEAK_MFMA_BF16_TFLOPS,
-                          "mfma_issue_frac": 3.0 * alg / PEAK_MFMA_BF16_TFLOPS})
+            if on_bf16:
+                r.update({"arithmetic": SPLIT_ARITH[name], "achieved": alg, "peak": PEAK_MFMA_BF16_TFLOPS,
+                          "frac": alg / PEAK_MFMA_BF16_TFLOPS, "mfma_issue_frac": ISSUE_MULT[name] * alg / PEAK_MFMA_BF16_TFLOPS})
             else:
                 r.update({"arithmetic": "fp32 MFMA", "achieved": alg, "peak": PEAK_MFMA_F32_TFLOPS,
                           "frac": alg / PEAK_MFMA_F32_TFLOPS})
-                if name in SPLIT_FAMILIES:
-                    r["kernel"] = name + ": the same launches with products on the fp32 matrix pipe (ddsp_ctx_set_math FP32)"
             return r
         present = [f for f in FAMILIES_TIMED if f in timed]
         order = sorted(present, key=lambda f: -timed[f]["ms_total"])

@@ -17,6 +17,7 @@ struct ddsp_table {
     int n0, n1;        // key
     float* dev;        // device pointer
     size_t bytes;
+    uint64_t last_use; // resample tap tables only: value of ddsp_ctx::table_clock at the last call that used it (LRU eviction)
 };
 
 // kernel families for the built-in HIP-event profiler (ddsp_profile_begin / _end)
@@ -48,6 +49,7 @@ struct ddsp_ctx {
     size_t scratch_used;
     ddsp_table tables[64];
     int n_tables;
+    uint64_t table_clock;
     // packed control-net weights (prepared by ddsp_u2c_prepare)
     float* packed;
     size_t packed_bytes;
@@ -106,8 +108,19 @@ struct ddsp_device_guard {
         if (!(cond)) return ddsp_fail(ctx, DDSP_ERR_ARG, msg, #cond);           \
     } while (0)
 
+// A launch helper that finds its arguments inconsistent (gemm::launch: operands that exist only pre-split on a path that
+// cannot read them) records it here instead of launching; the entry point's next DDSP_LAUNCH_CHECK turns it into an error
+// return (it used to abort() the host process).  Per thread, like the calls.
+inline const char*& ddsp_launch_refusal() {
+    static thread_local const char* what = nullptr;
+    return what;
+}
 #define DDSP_LAUNCH_CHECK(ctx)                                                  \
     do {                                                                        \
+        if (const char* r_ = ddsp_launch_refusal()) {                           \
+            ddsp_launch_refusal() = nullptr;                                    \
+            return ddsp_fail(ctx, DDSP_ERR_ARG, "kernel launch refused", r_);   \
+        }                                                                       \
         hipError_t e_ = hipGetLastError();                                      \
         if (e_ != hipSuccess) return ddsp_fail(ctx, DDSP_ERR_HIP, "kernel launch", hipGetErrorString(e_)); \
     } while (0)

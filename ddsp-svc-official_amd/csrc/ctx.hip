@@ -3,7 +3,7 @@
 
 #include <stdlib.h>
 
-#define DDSP_ABI_VERSION 3   // 2: ddsp_rss_loss takes the hops; 3: ddsp_conv1d / ddsp_nsf_mean emit activated (split) copies, kept-activation entry points
+#define DDSP_ABI_VERSION 4   // 2: ddsp_rss_loss takes the hops; 3: ddsp_conv1d / ddsp_nsf_mean emit activated (split) copies, kept-activation entry points; 4: ddsp_retime_f0
 
 extern "C" int ddsp_abi_version(void) { return DDSP_ABI_VERSION; }
 

@@ -49,7 +49,45 @@ __global__ void __launch_bounds__(256) align_units_kernel(const float* __restric
     }
 }
 
+// f0 track re-timed for the enhancer (enhancer.py:56-62): out[i] = numpy.interp(i * step_dst, knots j * step_num / div,
+// fl32(f0[j] * scale)) with the end values held outside the knots; one thread per output frame, fp64 like numpy.
+__global__ void __launch_bounds__(256) retime_f0_kernel(const float* __restrict__ f0, int64_t n_src, double step_num, double div,
+                                                        float scale, double step_dst, int64_t n_dst, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_dst) return;
+    auto knot = [&](int64_t j) { return (step_num * (double)j) / div; };              // (hop / sr) * arange(n) / real_factor
+    auto val = [&](int64_t j) { return (double)__fmul_rn(f0[j], scale); };            // the fp32 in-place `f0_np *= real_factor`
+    const double x = step_dst * (double)i;
+    double y;
+    if (n_src == 1 || x <= knot(0)) {
+        y = val(0);
+    } else if (x >= knot(n_src - 1)) {
+        y = val(n_src - 1);
+    } else {
+        int64_t j = (int64_t)(x * div / step_num);
+        j = j < 0 ? 0 : (j > n_src - 2 ? n_src - 2 : j);
+        while (j > 0 && knot(j) > x) --j;
+        while (j < n_src - 2 && knot(j + 1) <= x) ++j;
+        const double slope = (val(j + 1) - val(j)) / (knot(j + 1) - knot(j));
+        y = slope * (x - knot(j)) + val(j);
+    }
+    out[i] = (float)y;
+}
+
 }  // namespace
+
+extern "C" int ddsp_retime_f0(ddsp_ctx* ctx, void* stream, const float* f0, int64_t n_src, double step_num, double div,
+                              float scale, double step_dst, int64_t n_dst, float* out) {
+    DDSP_REQUIRE(ctx, ctx && f0 && out, "ddsp_retime_f0: null argument");
+    DDSP_REQUIRE(ctx, n_src >= 1 && n_dst >= 0 && step_num > 0 && div > 0 && step_dst > 0, "ddsp_retime_f0: bad shape or step");
+    if (n_dst == 0) return DDSP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DDSP_ENTER_DEVICE(ctx);
+    hipLaunchKernelGGL(retime_f0_kernel, dim3((unsigned)ceil_div64(n_dst, 256)), dim3(256), 0, st, f0, n_src, step_num, div, scale,
+                       step_dst, n_dst, out);
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}
 
 extern "C" int ddsp_volume_extract(ddsp_ctx* ctx, void* stream, const float* audio, int64_t B, int64_t T, int hop,
                                    float* volume) {

@@ -1,5 +1,5 @@
 // Plain GEMM entry point of the fp32-MFMA kernel: unit tests of the building block and tile/schedule A/B timing.
-#include "gemm_f32.h"
+#include "gemm_ws.h"
 
 extern "C" int ddsp_gemm_f32(ddsp_ctx* ctx, void* stream, const float* A, int64_t lda, int a_k_contig, const float* B,
                              int64_t ldb, int b_k_contig, const float* bias, float* C, int64_t ldc, int M, int N, int K,
@@ -20,7 +20,57 @@ extern "C" int ddsp_gemm_f32(ddsp_ctx* ctx, void* stream, const float* A, int64_
     else if (tile == 4) GO(128, 128, AK, BK_, 8);                            \
     else if (tile == 5) GO(128, 64, AK, BK_, 8);                             \
     else GO(256, 128, AK, BK_, 8);
-    if (tile >= 10) {
+    if (tile >= 70) {
+        // wave-specialised kernel (gemm_ws.h).  variant: 0 fp32 products, 3 split-bf16 (split in the loop), 8 TIMING ONLY (the
+        // operands are read as if already split: numbers meaningless); + 16: residual epilogue (C += ...), + 32: gated pair
+        // epilogue (C gets N / 2 columns); ablations (timing only): + 256 no MFMA, + 512 no DMA, + 1024 no stores
+        DDSP_REQUIRE(ctx, a_k_contig && b_k_contig && gemm::ws_ok(g, 5, (variant & 48) == 16), "ddsp_gemm_f32: ws tiles need row-major A, [N][K] B, K % 32 == 0, K >= 256, aligned rows");
+        const int math = variant & 15, kind = variant & 48, abl = variant >> 8;   // (abl up to 511)
+        DDSP_REQUIRE(ctx, (math == 0 || math == 3 || math == 8) && ((uintptr_t)C % 16) == 0 && ldc % 4 == 0 && N % 64 == 0, "ddsp_gemm_f32: ws variant");
+        hipError_t he = hipSuccess;
+#define WS(BM, BN, NS, MATH)                                                                                                   \
+        do {                                                                                                                   \
+            if (kind == 16) { DDSP_REQUIRE(ctx, false, "ws residual: tile 75"); }                                              \
+            else if (kind == 32) { gemm::WsGlu e2{C, ldc, bias}; DDSP_REQUIRE(ctx, bias && N % BN == 0 && BN == 128, "ws gated pair needs a bias and whole 128-column tiles"); \
+                if constexpr (BN == 128) he = gemm::launch_ws_one<BM, BN, gemm::WsGlu, NS, MATH, true>(st, g, e2); }           \
+            else { gemm::WsStore e2{C, ldc, bias};                                                                             \
+                he = (N % BN == 0) ? gemm::launch_ws_one<BM, BN, gemm::WsStore, NS, MATH, true>(st, g, e2)                     \
+                                   : gemm::launch_ws_one<BM, BN, gemm::WsStore, NS, MATH, false>(st, g, e2); }                 \
+        } while (0)
+#define WSM(BM, BN, NS)                                                     \
+        do {                                                                \
+            if (math == 0) WS(BM, BN, NS, 0);                               \
+            else if (math == 3) WS(BM, BN, NS, 3);                          \
+            else WS(BM, BN, NS, 8);                                         \
+        } while (0)
+        g.xcd = 1;
+        gemm::WsStore e0{C, ldc, bias};
+        if (abl) {
+            DDSP_REQUIRE(ctx, tile == 70 && kind == 0 && N % 128 == 0, "ws ablations: tile 70, plain store");
+            if (abl == 2) he = gemm::launch_ws_one<128, 128, gemm::WsStore, 4, 8, true, 2>(st, g, e0);
+            else if (abl == 4) he = gemm::launch_ws_one<128, 128, gemm::WsStore, 4, 8, true, 4>(st, g, e0);
+            else if (abl == 8) he = gemm::launch_ws_one<128, 128, gemm::WsStore, 4, 8, true, 8>(st, g, e0);
+            else if (abl == 16) he = gemm::launch_ws_one<128, 128, gemm::WsStore, 4, 8, true, 16>(st, g, e0);
+            else if (abl == 18) he = gemm::launch_ws_one<128, 128, gemm::WsStore, 4, 8, true, 18>(st, g, e0);
+            else if (abl == 32) he = gemm::launch_ws_one<128, 128, gemm::WsStore, 4, 8, true, 32>(st, g, e0);
+            else if (abl == 34) he = gemm::launch_ws_one<128, 128, gemm::WsStore, 4, 8, true, 34>(st, g, e0);
+            else if (abl == 50) he = gemm::launch_ws_one<128, 128, gemm::WsStore, 4, 8, true, 50>(st, g, e0);
+            else if (abl == 64) he = gemm::launch_ws_one<128, 128, gemm::WsStore, 4, 8, true, 64>(st, g, e0);
+            else if (abl == 178) he = gemm::launch_ws_one<128, 128, gemm::WsStore, 4, 8, true, 178>(st, g, e0);   // no DMA, lgkm, epilogue, LDS reads
+            else if (abl == 306) he = gemm::launch_ws_one<128, 128, gemm::WsStore, 4, 8, true, 306>(st, g, e0);   // no DMA, lgkm, epilogue, barriers
+            else if (abl == 434) he = gemm::launch_ws_one<128, 128, gemm::WsStore, 4, 8, true, 434>(st, g, e0);   // MFMAs only
+            else return ddsp_fail(ctx, DDSP_ERR_ARG, "ddsp_gemm_f32", "unknown ws ablation");
+        }
+        else if (tile == 70) WSM(128, 128, 4);
+        else if (tile == 72) { DDSP_REQUIRE(ctx, math == 8 && kind == 0 && N % 128 == 0, "tile 72: timing only"); he = gemm::launch_ws_one<128, 128, gemm::WsStore, 3, 8, true>(st, g, e0); }
+        else if (tile == 75) { DDSP_REQUIRE(ctx, math == 8 && kind != 32 && N % 64 == 0, "tile 75: timing only");
+            if (kind == 16) { gemm::WsResidual e2{C, C, ldc, bias}; he = gemm::launch_ws_one<128, 64, gemm::WsResidual, 5, 8, true>(st, g, e2); }
+            else he = gemm::launch_ws_one<128, 64, gemm::WsStore, 5, 8, true>(st, g, e0); }
+        else return ddsp_fail(ctx, DDSP_ERR_ARG, "ddsp_gemm_f32", "unknown ws tile");
+#undef WSM
+#undef WS
+        DDSP_HIP(ctx, he);
+    } else if (tile >= 10) {
         DDSP_REQUIRE(ctx, a_k_contig && b_k_contig && gemm::dma_ok(g), "ddsp_gemm_f32: DMA tiles need row-major A, [N][K] B, K % 32 == 0, aligned rows");
         if (tile == 10) gemm::launch_dma<128, 64>(st, g, 1, e);
         else if (tile == 11) gemm::launch_dma<128, 128>(st, g, 1, e);

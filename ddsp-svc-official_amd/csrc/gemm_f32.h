@@ -872,9 +872,9 @@ inline void launch(hipStream_t st, const Args& g, int batch, const Epi& epi) {
     if ((g.B_split && g.B_split == g.B) || g.A_split) {
         // operands that exist ONLY pre-split can be read by the DMA kernel alone (a caller that also has the fp32 matrix passes
         // it as B and lands here legitimately): the caller's size predicate and this function disagree
-        fprintf(stderr, "libddsp_amd: internal error: pre-split GEMM operands on the register-staged path (M=%d N=%d K=%d)\n",
-                g.M, g.N, g.K);
-        abort();
+        // nothing is launched; the caller's DDSP_LAUNCH_CHECK reports it (the outputs of this call are then undefined)
+        ddsp_launch_refusal() = "pre-split GEMM operands reached the register-staged path (size predicates disagree)";
+        return;
     }
     if (blocks(128, 64) >= 512)
         launch_tile<128, 64, A_KC, B_KC, A_MODE, Epi, 8>(st, g, batch, epi);

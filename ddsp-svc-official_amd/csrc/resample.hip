@@ -111,7 +111,12 @@ int gcd_int(int a, int b) {
 
 }  // namespace
 
-constexpr int TAB_RESAMPLE = 100;   // table kinds 100.. (tables.hip keeps 0..): key (orig/g) * 2^16 + (new/g), lowpass width
+// table kinds 100.. (tables.hip keeps 0..): key n0 = orig / g, n1 = (new / g) * 8192 + lowpass width (both fit an int: the
+// reduced rates are < 65536, the width <= 4096).  At most RS_TABLES_MAX tap tables live in a context: `Enhancer.enhance` with
+// adaptive_key='auto' asks for two new rate pairs per distinct key, so a long-running server evicts the least recently used
+// one (a hipFree, i.e. a device synchronisation, like the first use of any table) instead of filling the cache.
+constexpr int TAB_RESAMPLE = 100;
+constexpr int RS_TABLES_MAX = 8;
 
 extern "C" int64_t ddsp_resample_length(int64_t T, int orig_freq, int new_freq) {
     if (T < 0 || orig_freq < 1 || new_freq < 1) return -1;
@@ -137,13 +142,27 @@ extern "C" int ddsp_resample(ddsp_ctx* ctx, void* stream, const float* x, int64_
     const int width = (int)ceil((double)lowpass_filter_width * (double)orig / base);
     const int K = 2 * width + orig;
     DDSP_REQUIRE(ctx, (int64_t)nw * K < (1 << 28), "ddsp_resample: tap table too large");
-    // cached table: kind TAB_RESAMPLE, key (orig << 16 | new, lowpass width)
     float* taps = nullptr;
-    const int key0 = (orig << 16) | nw;
-    for (int i = 0; i < ctx->n_tables; ++i)
-        if (ctx->tables[i].kind == TAB_RESAMPLE && ctx->tables[i].n0 == key0 && ctx->tables[i].n1 == lowpass_filter_width)
-            taps = ctx->tables[i].dev;
+    const int key0 = orig, key1 = nw * 8192 + lowpass_filter_width;
+    const uint64_t now = ++ctx->table_clock;
+    int n_rs = 0, lru = -1;
+    for (int i = 0; i < ctx->n_tables; ++i) {
+        ddsp_table& t = ctx->tables[i];
+        if (t.kind != TAB_RESAMPLE) continue;
+        ++n_rs;
+        if (t.n0 == key0 && t.n1 == key1) {
+            taps = t.dev;
+            t.last_use = now;
+        } else if (lru < 0 || t.last_use < ctx->tables[lru].last_use) {
+            lru = i;
+        }
+    }
     if (!taps) {
+        if ((n_rs >= RS_TABLES_MAX || ctx->n_tables >= 64) && lru >= 0) {
+            // kernels of earlier calls may still read the evicted table: hipFree waits for the device
+            DDSP_HIP(ctx, hipFree(ctx->tables[lru].dev));
+            ctx->tables[lru] = ctx->tables[--ctx->n_tables];
+        }
         if (ctx->n_tables >= 64) return ddsp_fail(ctx, DDSP_ERR_OOM, "table cache full", "");
         const size_t bytes = (size_t)nw * K * sizeof(float);
         hipError_t e = hipMalloc((void**)&taps, bytes);
@@ -154,9 +173,10 @@ extern "C" int ddsp_resample(ddsp_ctx* ctx, void* stream, const float* x, int64_
         ddsp_table& t = ctx->tables[ctx->n_tables++];
         t.kind = TAB_RESAMPLE;
         t.n0 = key0;
-        t.n1 = lowpass_filter_width;
+        t.n1 = key1;
         t.dev = taps;
         t.bytes = bytes;
+        t.last_use = now;
     }
     const int64_t T_out = ((int64_t)nw * T + orig - 1) / orig;
     const int64_t total = B * T_out;

@@ -11,6 +11,7 @@
 // row-wise exp pass.  Everything else (GroupNorm, LayerNorm, GLU, depthwise k=31 conv + SiLU, embeddings,
 // weight-norm) is small fused elementwise / row-reduction kernels.
 #include "gemm_f32.h"
+#include "gemm_ws.h"
 #include "wgrad_bf16.h"
 #include "performer_attn.h"
 
@@ -1612,6 +1613,20 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
             g.A_split = a_is_split;
         }
     };
+    // Large batches: the wave-specialised kernel (gemm_ws.h: loader / product waves, epilogue pieces riding in the next tile)
+    // for the K = 256 Linear layers with wide outputs, once its 128x128 tiles make at least two rounds over the 256 CUs.  Same
+    // bits as kernel_dma.  Which layers: measured INSIDE the forward (rocprofv3, B = 64: DESIGN section 9) - the head gains
+    // (31.7 -> 28.4 us), QKV and pw1 + GLU do not (42.5 -> 43.9, 25.0 -> 27.9 us, although alone, with operands resident in the
+    // L2, they run 44.5 -> 38.8 and 30.0 -> 25.3), so only the head uses it.  DDSP_GEMM_WS = bit mask 1 QKV | 2 GLU | 4 head.
+    static int ws_mask = -1;
+    if (ws_mask < 0) {
+        const char* e = getenv("DDSP_GEMM_WS");
+        ws_mask = e ? atoi(e) : 4;
+    }
+    auto use_ws = [&](const gemm::Args& g, int layer_bit) {
+        return (ws_mask & layer_bit) && presplit_w && g.math == DDSP_MATH_SPLIT_BF16 && gemm::ws_ok(g) && g.N % 128 == 0 &&
+               (int64_t)((g.M + 127) / 128) * (g.N / 128) >= 512;
+    };
     bool conv_split = false;
     // ---- prenet: conv k3 -> GroupNorm(4) -> LeakyReLU -> conv k3 ----
     {
@@ -1679,8 +1694,14 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
             gemm::Args g = gemm::make(b.y, D, bf.wqkv + (size_t)l * 3 * INNER * D, D, iM, 3 * INNER, D);
             set_b(g, bf.wqkv + (size_t)l * 3 * INNER * D, asplit);
             EpiSplit3 e{{b.q, b.k, b.v}, bf.bqkv + (size_t)l * 3 * INNER};
-            PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * 3 * INNER * D, 4.0 * M * (D + 3 * INNER),
-                 (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
+            gemm::WsSplit3 ew{{b.q, b.k, b.v}, bf.bqkv + (size_t)l * 3 * INNER};
+            if (use_ws(g, 1) && ew.vec_ok()) {
+                PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * 3 * INNER * D, 4.0 * M * (D + 3 * INNER),
+                     DDSP_HIP(ctx, (gemm::ws_go<128, 128, gemm::WsSplit3, 4>(st, g, ew))));
+            } else {
+                PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * 3 * INNER * D, 4.0 * M * (D + 3 * INNER),
+                     (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
+            }
         }
         if (attn_bf16) {
             // inference, split-bf16 products, enough (utterance, head) pairs to fill the chip with one workgroup each:
@@ -1767,8 +1788,14 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
             set_b(g, bf.wglu + (size_t)l * 2 * INNER * D, asplit);
             EpiGlu e{b.glu, bf.bglu + (size_t)l * 2 * INNER};
             DDSP_REQUIRE(ctx, gemm::dma_ok(g) && ((uintptr_t)b.glu % 16) == 0, "unit2ctrl: fused GLU needs aligned activations");
-            PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * 2 * INNER * D, 4.0 * M * (D + INNER),
-                 (gemm::dma_go<128, 128, EpiGlu, 2>(st, g, 1, e)));
+            gemm::WsGlu ew{b.glu, INNER, bf.bglu + (size_t)l * 2 * INNER};
+            if (use_ws(g, 2) && ew.vec_ok()) {
+                PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * 2 * INNER * D, 4.0 * M * (D + INNER),
+                     DDSP_HIP(ctx, (gemm::ws_go<128, 128, gemm::WsGlu, 4>(st, g, ew))));
+            } else {
+                PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * 2 * INNER * D, 4.0 * M * (D + INNER),
+                     (gemm::dma_go<128, 128, EpiGlu, 2>(st, g, 1, e)));
+            }
         } else {
             {
                 gemm::Args g = gemm::make(b.y2, D, L.cm_pw1_w, D, iM, 2 * INNER, D);
@@ -1802,8 +1829,14 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         gemm::Args g = gemm::make(bf.y_final, D, bf.wh, D, iM, w.n_out, D);
         set_b(g, bf.wh, asplit);
         gemm::EpiStore e{ctrl, w.n_out, w.head_b, 1, 0, 0};
-        PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * w.n_out * D, 4.0 * M * (D + w.n_out),
-             (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
+        gemm::WsStore ew{ctrl, w.n_out, w.head_b};
+        if (use_ws(g, 4) && ew.vec_ok()) {
+            PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * w.n_out * D, 4.0 * M * (D + w.n_out),
+                 DDSP_HIP(ctx, (gemm::ws_go<128, 128, gemm::WsStore, 4>(st, g, ew))));
+        } else {
+            PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * w.n_out * D, 4.0 * M * (D + w.n_out),
+                 (gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e)));
+        }
     }
     DDSP_LAUNCH_CHECK(ctx);
     return DDSP_OK;

@@ -188,11 +188,12 @@ class Unit2Control(nn.Module):
         w, keep = self._weights_struct()
         g = hipddsp.U2CWeights()
         grads = {}
-        # `training.GradBucket` sets `_grads_in_place`: the library then writes every gradient straight into the
-        # parameter's `.grad` (a view of the bucket's flat buffer) and autograd gets nothing to accumulate - no per-parameter
-        # add launches (0.18 ms of a B = 32 step).  The library WRITES gradients, so this is for the one-backward-per-step
-        # flow of `training.train_step` only.
+        # `training.GradBucket.zero()` arms `_grads_in_place`: the library then writes every gradient straight into the
+        # parameter's `.grad` (a view of the bucket's freshly zeroed flat buffer) and autograd gets nothing to accumulate - no
+        # per-parameter add launches (0.18 ms of a B = 32 step).  The library WRITES (`=`), so the token is consumed here: a
+        # second backward pass before the next `zero()` returns its gradients to autograd, which accumulates them.
         in_place = getattr(self, "_grads_in_place", False)
+        self._grads_in_place = False
         for name, t in self._named_tensors():
             if name.endswith("_proj"):
                 continue

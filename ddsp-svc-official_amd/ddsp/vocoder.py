@@ -148,9 +148,10 @@ class _SynthTrainFn(torch.autograd.Function):
     def forward(fctx, model, units, f0_frames, volume, spk_id, spk_mix_dict, initial_phase, infer, noise, noise_seed,
                 *params):
         ctx, ps = model._front(f0_frames, initial_phase, infer, model._comb_mode, **model._front_wants)
-        # the training forward runs fp32 products throughout (control network, filter synthesis, FIR): the backward call
-        # re-runs the control network in fp32 to rebuild its activations and the adjoints multiply in fp32, and the loss
-        # gradient amplifies a 4e-6 disagreement between the two passes a thousandfold (tools/diag_train_b32.py)
+        # the training forward runs fp32 products throughout (control network, filter synthesis, FIR): the loss gradient
+        # amplifies a 4e-6 error of the signal a thousandfold (tools/diag_train_b32.py).  The BACKWARD runs on the
+        # context's own mode: its weight / input gradient GEMMs use split-bf16 products by default (a 4e-6 product error
+        # inside the backward is not amplified); `ctx.set_math(MATH_FP32)` around `loss.backward()` makes them fp32 too
         keep_math = ctx.math
         ctx.set_math(hipddsp.MATH_FP32)
         try:

@@ -353,42 +353,51 @@ class Enhancer:
         self.enhancer_sample_rate = self.enhancer.sample_rate()
         self.enhancer_hop_size = self.enhancer.hop_size()
 
-    def enhance(self, audio, sample_rate, f0, hop_size, adaptive_key=0, silence_front=0, rand_ini=None):
-        """audio (1,T), f0 (1,n_frames,1) -> (enhanced (1,T'), enhancer sample rate)."""
-        start_frame = int(silence_front * sample_rate / hop_size)
-        real_silence_front = start_frame * hop_size / sample_rate
-        audio = audio[:, int(np.round(real_silence_front * sample_rate)):]
-        f0 = f0[:, start_frame:, :]
-        if adaptive_key == "auto":
-            adaptive_key = 12 * np.log2(float(torch.max(f0) / 760))
-            adaptive_key = max(0, np.ceil(adaptive_key))
+    # -- the three decisions of `enhance` that do not touch audio ------------------------------------------------------
+    @staticmethod
+    def _front_cut(silence_front, sample_rate, hop_size):
+        """(frames, samples, seconds) of the silent front that is skipped and padded back (enhancer.py:27-31,76-77)."""
+        frames = int(silence_front * sample_rate / hop_size)
+        seconds = frames * hop_size / sample_rate
+        return frames, int(np.round(seconds * sample_rate)), seconds
+
+    def _working_rate(self, adaptive_key, f0):
+        """The rate the generator is run at for a key shift of `adaptive_key` semitones (enhancer.py:33-43): the audio is
+        treated as if sampled at 100 * round(sr_e * 2^(key/12) / 100) Hz, which moves every pitch down by the key.
+        'auto' picks the smallest non-negative key that brings the highest f0 under 760 Hz - that one number decides
+        tensor LENGTHS, so it is the single value read back from the device (a max over a few hundred frames)."""
+        if isinstance(adaptive_key, str):
+            if adaptive_key != "auto":
+                raise ValueError(f"adaptive_key must be a number or 'auto', got {adaptive_key!r}")
+            adaptive_key = max(0, np.ceil(12 * np.log2(float(torch.max(f0) / 760))))
             print("auto_adaptive_key: " + str(int(adaptive_key)))
-        else:
-            adaptive_key = float(adaptive_key)
-        adaptive_factor = 2 ** (-adaptive_key / 12)
-        adaptive_sample_rate = 100 * int(np.round(self.enhancer_sample_rate / adaptive_factor / 100))
-        real_factor = self.enhancer_sample_rate / adaptive_sample_rate
-        if sample_rate == adaptive_sample_rate:
-            audio_res = audio
-        else:
-            key = str(sample_rate) + str(adaptive_sample_rate)
-            if key not in self.resample_kernel:
-                self.resample_kernel[key] = Resample(sample_rate, adaptive_sample_rate, lowpass_filter_width=128)
-            audio_res = self.resample_kernel[key](audio)
+        shrink = 2 ** (-float(adaptive_key) / 12)
+        rate = 100 * int(np.round(self.enhancer_sample_rate / shrink / 100))
+        return rate, self.enhancer_sample_rate / rate, shrink
+
+    def _resampled(self, x, rate_in, rate_out):
+        if rate_in == rate_out:
+            return x
+        pair = (int(rate_in), int(rate_out))
+        if pair not in self.resample_kernel:
+            self.resample_kernel[pair] = Resample(rate_in, rate_out, lowpass_filter_width=128)
+        return self.resample_kernel[pair](x)
+
+    def enhance(self, audio, sample_rate, f0, hop_size, adaptive_key=0, silence_front=0, rand_ini=None):
+        """audio (1,T), f0 (1,n_frames,1) -> (enhanced (1,T'), enhancer sample rate); reference `enhancer.py:24-78`.
+        Device only: the f0 track is re-timed to the generator's frames by `ddsp_retime_f0`, nothing is copied to the host
+        (with adaptive_key='auto' one scalar - the highest f0 - is read back, see `_working_rate`)."""
+        cut_frames, cut_samples, cut_seconds = self._front_cut(silence_front, sample_rate, hop_size)
+        audio, f0 = audio[:, cut_samples:], f0[:, cut_frames:, :]
+        work_rate, pitch_scale, shrink = self._working_rate(adaptive_key, f0)
+        audio_res = self._resampled(audio, sample_rate, work_rate)
         n_frames = int(audio_res.size(-1) // self.enhancer_hop_size + 1)
-        # the f0 track is re-timed on the host like the reference does (numpy interp over a few hundred frames)
-        f0_np = f0.squeeze(0).squeeze(-1).cpu().numpy().copy()
-        f0_np *= real_factor
-        time_org = (hop_size / sample_rate) * np.arange(len(f0_np)) / real_factor
-        time_frame = (self.enhancer_hop_size / self.enhancer_sample_rate) * np.arange(n_frames)
-        f0_res = np.interp(time_frame, time_org, f0_np, left=f0_np[0], right=f0_np[-1])
-        f0_res = torch.from_numpy(f0_res).unsqueeze(0).float().to(audio.device)
+        # f0 of frame i of the generator = the track (scaled by pitch_scale, its time axis divided by it) at i * hop_e / sr_e
+        f0_res = hipddsp.context_for(audio.device).retime_f0(f0, hop_size / sample_rate, pitch_scale, pitch_scale,
+                                                               self.enhancer_hop_size / self.enhancer_sample_rate, n_frames)[None]
         enhanced, sr_e = self.enhancer(audio_res, f0_res, rand_ini=rand_ini)
-        if adaptive_factor != 0:
-            key = str(adaptive_sample_rate) + str(sr_e)
-            if key not in self.resample_kernel:
-                self.resample_kernel[key] = Resample(adaptive_sample_rate, sr_e, lowpass_filter_width=128)
-            enhanced = self.resample_kernel[key](enhanced)
-        if start_frame > 0:
-            enhanced = F.pad(enhanced, (int(np.round(sr_e * real_silence_front)), 0))
+        if shrink != 0:
+            enhanced = self._resampled(enhanced, work_rate, sr_e)
+        if cut_frames > 0:
+            enhanced = F.pad(enhanced, (int(np.round(sr_e * cut_seconds)), 0))
         return enhanced, sr_e

@@ -22,7 +22,7 @@ FIR_FP32, FIR_SPLIT_BF16 = 0, 3   # ddsp_ltv_fir `math` (include/ddsp_amd.h)
 MATH_FP32, MATH_SPLIT_BF16 = 0, 3  # ddsp_ctx_set_math
 
 _c = ctypes
-_vp, _i64, _u64, _int, _f32 = _c.c_void_p, _c.c_int64, _c.c_uint64, _c.c_int, _c.c_float
+_vp, _i64, _u64, _int, _f32, _f64 = _c.c_void_p, _c.c_int64, _c.c_uint64, _c.c_int, _c.c_float, _c.c_double
 
 
 class U2CWeights(_c.Structure):
@@ -89,6 +89,7 @@ SIGNATURES = {
     "ddsp_phase_vocoder": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
     "ddsp_volume_extract": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp]),
     "ddsp_align_units": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp]),
+    "ddsp_retime_f0": (_int, [_vp, _vp, _vp, _i64, _f64, _f64, _f32, _f64, _i64, _vp]),
     "ddsp_resample_length": (_i64, [_i64, _int, _int]),
     "ddsp_resample": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _int, _vp]),
     "ddsp_conv1d": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _vp, _vp, _vp, _f32, _vp, _int]),
@@ -421,6 +422,15 @@ class Context:
         self.call("ddsp_align_units", _ptr(units), B, Lu, C, int(n_frames), float(ratio), _ptr(out))
         return out
 
+    def retime_f0(self, f0, step_num, div, scale, step_dst, n_dst):
+        """f0 (n,) device track -> (n_dst,): numpy.interp(i * step_dst; knots (step_num * j) / div, values fl32(f0 * scale)),
+        end values held (enhancer.py:56-62), without leaving the device."""
+        f0 = f0.reshape(-1).contiguous().float()
+        out = torch.empty(int(n_dst), device=f0.device, dtype=torch.float32)
+        self.call("ddsp_retime_f0", _ptr(f0), f0.numel(), float(step_num), float(div), float(scale), float(step_dst), int(n_dst),
+                  _ptr(out))
+        return out
+
     # -- SURVEY 8(f) rank 3: sample-rate conversion ---------------------------------------------
     def resample(self, audio, orig_freq, new_freq, lowpass_filter_width=6):
         """audio (B,T) or (T,) -> (B, ceil(T*new/orig)): windowed-sinc polyphase (torchaudio.transforms.Resample's algorithm)."""
@@ -517,11 +527,14 @@ class Context:
                   float(beta1), float(beta2), float(eps), float(weight_decay), int(step))
 
     # -- building block ------------------------------------------------------------------------
-    def gemm(self, A, B, bias=None, a_k_contig=True, b_k_contig=True, tile=0, variant=0):
-        """C = op(A) @ op(B) (+bias): A (M,K) or (K,M) when not a_k_contig; B (N,K) or (K,N) when not b_k_contig."""
+    def gemm(self, A, B, bias=None, a_k_contig=True, b_k_contig=True, tile=0, variant=0, out=None):
+        """C = op(A) @ op(B) (+bias): A (M,K) or (K,M) when not a_k_contig; B (N,K) or (K,N) when not b_k_contig.
+        `out`: an (M, N) matrix to write into (the residual variants of the wave-specialised tiles ADD to it)."""
         M, K = (A.shape if a_k_contig else A.shape[::-1])
         N = B.shape[0] if b_k_contig else B.shape[1]
-        C = torch.empty(M, N, device=A.device, dtype=torch.float32)
+        C = torch.empty(M, N, device=A.device, dtype=torch.float32) if out is None else out
+        if C.shape != (M, N) or C.dtype != torch.float32 or not C.is_contiguous():
+            raise ValueError("gemm: `out` must be a contiguous fp32 (M, N) matrix")
         for t in (A, B):
             if not t.is_cuda or t.stride(1) != 1 or t.dtype != torch.float32:
                 raise ValueError("gemm operands must be fp32 device matrices with unit inner stride")

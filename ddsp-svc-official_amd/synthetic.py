@@ -54,10 +54,13 @@ MODEL_CFG = {
 }
 
 
-def build_model(name, seed=BASE_SEED, device="cpu"):
-    """Constructs the product module with seeded random weights (reference state-dict shapes)."""
+def build_model(name, seed=BASE_SEED, device="cpu", n_unit=None):
+    """Constructs the product module with seeded random weights (reference state-dict shapes).  `n_unit` overrides the
+    encoder width (configs/combsub_xunit.yaml: 4, combsub_yunit.yaml: 512, reference `data.encoder_out_channels`)."""
     from ddsp.vocoder import CombSub, CombSubFast, Sins
-    cfg = MODEL_CFG[name]
+    cfg = dict(MODEL_CFG[name])
+    if n_unit is not None:
+        cfg["n_unit"] = int(n_unit)
     gen_state = torch.random.get_rng_state()
     torch.manual_seed(seed)
     try:

@@ -70,7 +70,8 @@ class GradBucket:
 
     def __init__(self, params, model=None):
         """`model`: the synthesiser whose parameters these are - its control network then receives its gradients directly
-        in the bucket (`Unit2Control._grads_in_place`) instead of through autograd's accumulation."""
+        in the bucket (`Unit2Control._grads_in_place`, a one-shot token that `zero()` arms) instead of through autograd's
+        accumulation."""
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         ref = self.params[0]
@@ -79,11 +80,16 @@ class GradBucket:
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
-        if model is not None and hasattr(model, "unit2ctrl"):
-            model.unit2ctrl._grads_in_place = True
+        self._net = model.unit2ctrl if model is not None and hasattr(model, "unit2ctrl") else None
 
     def zero(self):
+        """Zero every gradient and ARM the control network's direct write for the NEXT backward pass only: the library
+        overwrites (`=`) the bucket's views instead of handing gradients to autograd, which is right exactly once per
+        zeroed bucket.  A second backward before the next `zero()` (micro-batches, two losses) finds the token spent and
+        goes through autograd's accumulation again (`Unit2Control.backward_flat`)."""
         self.flat.zero_()
+        if self._net is not None:
+            self._net._grads_in_place = True
 
     def allreduce(self, world, group=None):
         """Mean over the ranks, one all_reduce (RCCL over xGMI on GPUs)."""

@@ -48,9 +48,13 @@ int ddsp_ctx_poll_error(ddsp_ctx* ctx);
  *   DDSP_MATH_SPLIT_BF16 (default): every fp32 product from three bf16 matrix products (hi*hi + hi*lo + lo*hi), fp32
  *                         accumulation, ~4e-6 relative error per contraction - narrower than the reference's fp32;
  *   DDSP_MATH_FP32:       fp32 matrix products (v_mfma_f32_*_f32), ~3e-7 - the reference's precision class.
- * Training (ddsp_unit2ctrl_bwd and every *_bwd entry point) always uses fp32 products; the Python mirror also runs the
- * control network's training FORWARD in fp32 (the backward call rebuilds its activations in fp32).  GEMMs whose shape
- * keeps them off the LDS-DMA kernel (K not a multiple of 32, unaligned rows) run fp32 products in either mode. */
+ * Training: the weight-gradient and input-gradient GEMMs of ddsp_unit2ctrl_bwd / ddsp_unit2ctrl_bwd_kept FOLLOW this mode
+ * too (split-bf16 by default: transposed pre-split weight copies, wgrad_bf16.h); the attention / FIR / filter-synthesis
+ * adjoints, the spectral loss and every activation a backward call rebuilds use fp32 products in either mode.  A caller that
+ * needs reference-class fp32 gradients sets DDSP_MATH_FP32 around the backward call as well.  The Python mirror runs the
+ * training FORWARD in fp32 products (dL/dsignal amplifies a 4e-6 disagreement between forward and backward) and leaves the
+ * backward on the context's mode.  GEMMs whose shape keeps them off the LDS-DMA kernel (K not a multiple of 32, unaligned
+ * rows) run fp32 products in either mode. */
 #define DDSP_MATH_FP32 0
 #define DDSP_MATH_SPLIT_BF16 3
 int ddsp_ctx_set_math(ddsp_ctx* ctx, int math);
@@ -255,6 +259,12 @@ int ddsp_volume_extract(ddsp_ctx* ctx, void* stream, const float* audio, int64_t
  * round half to even (torch.round); units (B,Lu,C) -> out (B,n_frames,C). */
 int ddsp_align_units(ddsp_ctx* ctx, void* stream, const float* units, int64_t B, int64_t Lu, int64_t C,
                      int64_t n_frames, float ratio, float* out);
+
+/* replaces the host-side f0 re-timing of enhancer.py:56-62 (`f0_np *= real_factor`; `np.interp(time_frame, time_org, f0_np,
+ * left=f0_np[0], right=f0_np[-1])`): out[i] = interp(i * step_dst) over the knots x_j = (step_num * j) / div with values
+ * fl32(f0[j] * scale), evaluated in fp64 like numpy; f0 (n_src,) -> out (n_dst,).  No host copy of the track. */
+int ddsp_retime_f0(ddsp_ctx* ctx, void* stream, const float* f0, int64_t n_src, double step_num, double div, float scale,
+                   double step_dst, int64_t n_dst, float* out);
 
 /* ---- sample-rate conversion ------------------------------------------------------ */
 /* replaces `torchaudio.transforms.Resample(orig_freq, new_freq, lowpass_filter_width)` as the reference uses it (gui.py:399-404,

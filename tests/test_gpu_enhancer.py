@@ -180,6 +180,8 @@ def test_enhancer_end_to_end(dev, lib_path, tmp_path):
         rsf = start * hop / sr
         audio = audio[:, int(np.round(rsf * sr)):]
         f0 = f0[:, start:, :]
+        if key == "auto":
+            key = max(0, np.ceil(12 * np.log2(float(torch.max(f0) / 760))))
         fac = 2 ** (-float(key) / 12)
         asr = 100 * int(np.round(44100 / fac / 100))
         rf = 44100 / asr
@@ -199,13 +201,64 @@ def test_enhancer_end_to_end(dev, lib_path, tmp_path):
     T, hop = 4096, 512
     audio = GC.nsf_audio(T)
     f0 = torch.full((1, T // hop, 1), 300.0)
-    for key, sf in ((0, 0), (4, 0), (0, 0.03)):
-        got, sr_o = enh.enhance(audio.to(dev), 44100, f0.to(dev), hop, adaptive_key=key, silence_front=sf, rand_ini=ri)
-        want = cpu_pipeline(audio, 44100, f0, hop, key, sf)
+    # a track that is not constant (the re-timing interpolates) and peaks at 1000 Hz: adaptive_key='auto' (enhancer.py:34-38)
+    # then picks ceil(12 log2(1000 / 760)) = 5 semitones; the flat 300 Hz track leaves 'auto' at key 0
+    f0_var = (300.0 + 700.0 * torch.sin(torch.arange(T // hop) / 2.5) ** 2).reshape(1, -1, 1)
+    assert float(f0_var.max()) > 990
+    for key, sf, track in ((0, 0, f0), (4, 0, f0), (0, 0.03, f0), ("auto", 0, f0), ("auto", 0, f0_var), (2, 0.03, f0_var)):
+        got, sr_o = enh.enhance(audio.to(dev), 44100, track.to(dev), hop, adaptive_key=key, silence_front=sf, rand_ini=ri)
+        want = cpu_pipeline(audio, 44100, track, hop, key, sf)
         assert sr_o == 44100 and got.shape == want.shape, (key, sf, got.shape, want.shape)
         assert float((got.cpu() - want).abs().max()) < 5e-4, (key, sf)
     with pytest.raises(ValueError):
+        enh.enhance(audio.to(dev), 44100, f0.to(dev), hop, adaptive_key="automatic")
+    with pytest.raises(ValueError):
         Enhancer("other", str(tmp_path / "model"))
+
+
+def test_retime_f0_against_numpy(ctx, dev):
+    """`ddsp_retime_f0` against the reference's host expression (enhancer.py:56-62): scaled fp32 values, fp64 knots, numpy.interp
+    with held ends - for up-, down- and same-rate grids, a single-frame track and targets beyond both ends."""
+    rng = np.random.Generator(np.random.PCG64(31))
+    for n, hop, sr, factor, hop_e, sr_e, n_dst in [(173, 512, 44100, 1.0, 512, 44100, 173), (87, 512, 44100, 44100 / 55600, 512, 44100, 120),
+                                                   (40, 441, 44100, 1.26, 32, 44100, 700), (1, 512, 44100, 0.9, 512, 44100, 5),
+                                                   (500, 160, 16000, 0.7071, 512, 44100, 431)]:
+        f0 = (rng.uniform(60, 900, n)).astype(np.float32)
+        f0[n // 3: n // 3 + 2] = 0.0
+        vals = f0.copy()
+        vals *= factor
+        t_org = (hop / sr) * np.arange(n) / factor
+        t_dst = (hop_e / sr_e) * np.arange(n_dst)
+        want = np.interp(t_dst, t_org, vals, left=vals[0], right=vals[-1]).astype(np.float32)
+        got = ctx.retime_f0(torch.from_numpy(f0).to(dev), hop / sr, factor, factor, hop_e / sr_e, n_dst).cpu().numpy()
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 1e-6 * max(1.0, np.abs(want).max()), (n, np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("math", ["split_bf16", "fp32"])
+def test_generator_shipped_geometry(ctx, dev, lib_path, math):
+    """The geometry that is benchmarked and shipped with the reference's pretrained enhancer (nsf_hifigan config: 512 initial
+    channels, upsample rates 8-8-2-2-2 with kernels 16-16-4-4-4, 128 mels, resblock kernels 3 / 7 / 11, dilations 1 / 3 / 5;
+    nsf_hifigan/models.py:219-276) on 24 frames against the oracle generator, in both product arithmetics.  This is the
+    configuration that selects the 128x128 and 64x128 tiles of the wide stages and the 32-channel bf16-fragment kernel."""
+    import hipddsp
+    from enhancer import AttrDict, Generator
+    cfg = dict(GC.NSF_CONFIG, upsample_rates=[8, 8, 2, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4, 4], upsample_initial_channel=512,
+               num_mels=128, hop_size=512, n_fft=2048, win_size=2048)
+    sd = GC.nsf_state_dict(cfg, seed=91)
+    mel, f0, ri = GC.nsf_inputs(cfg, L=24, seed=92)
+    want = OE.generator(sd, cfg, mel, f0, ri)
+    gen = Generator(AttrDict(cfg), sd)
+    ctx.set_math(hipddsp.MATH_SPLIT_BF16 if math == "split_bf16" else hipddsp.MATH_FP32)
+    try:
+        got = gen(mel.to(dev), f0.to(dev), rand_ini=ri[0])
+    finally:
+        ctx.set_math(hipddsp.MATH_SPLIT_BF16)
+    assert got.shape == want.shape == (1, 1, 24 * 512)
+    scale = float(want.abs().max())
+    err = float((got.cpu() - want).abs().max())
+    assert scale > 1e-3 and err < (3e-4 if math == "split_bf16" else 1e-4) * max(1.0, scale), (err, scale)
+    assert rms(got.cpu() - want) < (3e-5 if math == "split_bf16" else 1e-5) * max(1.0, rms(want) / 0.1), (rms(got.cpu() - want), rms(want))
 
 
 def test_noise_conv_building_block(ctx, dev):

@@ -51,3 +51,48 @@ def test_dma_requires_alignment(ctx, dev):
     A, B = _mk((64, 36), 7, dev), _mk((64, 36), 8, dev)
     with pytest.raises(ValueError):
         ctx.gemm(A, B, tile=10)        # K % 32 != 0
+
+
+# ---- the wave-specialised kernel (csrc/gemm_ws.h): tiles 70+ ---------------------------------------------------------
+def _presplit(X):
+    """(rows, K) fp32 -> the (8 bf16 hi | 8 bf16 lo) operand layout with lo = 0, and the bf16-rounded values it encodes."""
+    Xb = X.to(torch.bfloat16)
+    hi = Xb.view(torch.int16).view(-1, X.shape[1] // 8, 8)
+    return torch.cat([hi, torch.zeros_like(hi)], dim=2).reshape(X.shape[0], -1).view(torch.float32).contiguous(), Xb.float()
+
+
+@pytest.mark.parametrize("M,N,K", [(11008, 1536, 256), (11008 // 4, 1024, 256), (1000, 256, 256), (300, 384, 512),
+                                   (128 * 5 + 7, 1024, 768), (129, 128, 1024)])
+def test_wave_specialised_kernel(ctx, dev, M, N, K):
+    """Loader / product waves on an LDS ring, epilogue pieces riding in the next tile: fp32 and split-bf16 products against
+    fp64 and BIT-IDENTICAL to the round-2 LDS-DMA kernel (same order of partial sums), the gated-pair epilogue, the residual
+    epilogue whose operand the loader waves fetch into the LDS; ragged row counts, one to many tiles per workgroup."""
+    A, B, bias = _mk((M, K), 14, dev), _mk((N, K), 15, dev), _mk((N,), 16, dev)
+    ref = A.double() @ B.double().t() + bias.double()
+    scale = float(ref.abs().max())
+    c0 = ctx.gemm(A, B, bias, tile=70, variant=0)
+    c3 = ctx.gemm(A, B, bias, tile=70, variant=3)
+    assert float((c0.double() - ref).abs().max()) < 2e-6 * scale * max(1.0, K ** 0.5 / 4)
+    assert float((c3.double() - ref).abs().max()) < 3e-5 * scale
+    assert torch.equal(c0, ctx.gemm(A, B, bias, tile=13)) and torch.equal(c3, ctx.gemm(A, B, bias, tile=30))
+    for _ in range(3):
+        assert torch.equal(ctx.gemm(A, B, bias, tile=70, variant=3), c3)
+    if N % 128 == 0:
+        cg = ctx.gemm(A, B, bias, tile=70, variant=3 + 32)[:, : N // 2]
+        full = ref.view(M, N // 64, 2, 32)
+        want = (full[:, :, 0] * torch.sigmoid(full[:, :, 1])).reshape(M, N // 2)
+        # d(a sigmoid(g)) <= |da| + |a| |dg| / 4 with |da|, |dg| ~ 5e-6 * scale for three-product split-bf16
+        assert float((cg.double() - want).abs().max()) < 1e-5 * scale * (1 + 0.25 * scale)
+    if K >= 32 * 13:
+        As, Ab = _presplit(A)
+        Bs, Bb = _presplit(B)
+        out = _mk((M, N), 17, dev)
+        want = out.double() + Ab.double() @ Bb.double().t() + bias.double()
+        got = ctx.gemm(As, Bs, bias, tile=75, variant=8 + 16, out=out.clone())
+        assert float((got.double() - want).abs().max()) < 2e-6 * float(want.abs().max())
+
+
+def test_wave_specialised_kernel_rejects_short_k(ctx, dev):
+    A, B = _mk((256, 128), 7, dev), _mk((128, 128), 8, dev)
+    with pytest.raises(ValueError):
+        ctx.gemm(A, B, tile=70)        # K < 256: a tile's epilogue rides in eight k-steps of the next

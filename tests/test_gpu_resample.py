@@ -56,3 +56,24 @@ def test_resample_module_mirror(dev, lib_path):
         rs(x.cpu())
     with pytest.raises(ValueError):
         Resample(44100, 48000, resampling_method="sinc_interp_kaiser")
+
+
+def test_resample_table_cache_evicts(ctx, dev):
+    """tap tables are cached per context, least recently used evicted beyond eight (a server running
+    `Enhancer.enhance(adaptive_key='auto')` keeps asking for new rate pairs).  Twenty distinct pairs, the first one used again
+    at the end (re-built after its eviction), a pair whose reduced `orig` is >= 32768 (the old key overflowed an int)."""
+    x = _signal(5, 1, 3000, 44100)
+    first = None
+    for i in range(20):
+        new = 44100 + 100 * (i + 1)
+        got = ctx.resample(x.to(dev), 44100, new, 16)
+        if i == 0:
+            first = got.clone()
+    again = ctx.resample(x.to(dev), 44100, 44200, 16)
+    assert torch.equal(again, first)
+    want = OR.resample(x, 44100, 44200, 16, dtype=torch.float64)
+    assert float((again.cpu().double() - want).abs().max()) < 3e-6
+    y = _signal(6, 1, 40000, 40001)[:, :40000]
+    got = ctx.resample(y.to(dev), 40001, 3, 4)               # reduced rates 40001 / 3
+    want = OR.resample(y, 40001, 3, 4, dtype=torch.float64)
+    assert got.shape == want.shape and float((got.cpu().double() - want).abs().max()) < 3e-6 * max(1.0, float(want.abs().max()))

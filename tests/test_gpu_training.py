@@ -250,6 +250,16 @@ def test_train_step_bench_batch_against_autograd(dev, lib_path):
     crit.set_scales(scales)
     loss = crit(sig.detach(), target.to(dev))
     assert abs(float(loss) - float(loss_o.detach())) < 5e-5 * float(loss_o.detach()), (float(loss), float(loss_o.detach()))
+    # the mode solver.py:111 actually runs (`infer=False`: fp32-rounded running phase) at full size: waveform and loss value
+    with torch.no_grad():
+        sig_to = OS.combsub_forward(sd0, cfg, inp["units"], inp["f0"], inp["volume"], inp["spk_id"], infer=False,
+                                    noise=inp["noise"])[0]
+        loss_to = OL.rss_loss(sig_to, target, scales)
+        sig_t = model(d["units"], d["f0"], d["volume"], d["spk_id"], infer=False, noise=d["noise"])[0]
+        e_t = float((sig_t.cpu() - sig_to).double().pow(2).mean().sqrt())
+        assert e_t < 1e-4, (e_t, float(sig_to.double().pow(2).mean().sqrt()))          # the north_star gate, train mode
+        loss_t = crit(sig_t, target.to(dev))
+    assert abs(float(loss_t) - float(loss_to)) < 5e-5 * float(loss_to), (float(loss_t), float(loss_to))
     # the loss kernel at full size, at the oracle's signal
     _, g = hipddsp.context_for(dev).rss_loss(sig_o.detach().to(dev), target.to(dev), scales, want_grad=True)
     assert _rel(g.cpu(), x64.grad) < max(3 * cpu_err, 4e-3), (_rel(g.cpu(), x64.grad), cpu_err)
@@ -285,3 +295,65 @@ def test_grad_bucket_train_step_equals_plain(dev, lib_path):
     assert outs[0][0] == outs[1][0]
     for a, b in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a, b)
+
+
+def test_first_step_gradients_fp32_throughout_against_reference_run(dev, lib_path):
+    """the backward GEMMs follow the context's math mode (split-bf16 by default).  With `set_math(MATH_FP32)` around
+    forward AND backward every product of the step is fp32 - the reference's precision class - and the per-parameter gradient
+    norms of iteration 0 are held to the reference run (ref_train_step.npz) tighter than in the default mode."""
+    import os
+    import glue_cases as GC
+    import hipddsp
+    from conftest import GOLDEN
+    from ddsp.loss import RSSLoss
+    z = np.load(os.path.join(GOLDEN, "ref_train_step.npz"))
+    batch = {k: v.to(dev) for k, v in synthetic.make_inputs(GC.TRAIN_INPUT_SEED, GC.TRAIN_B, GC.TRAIN_FR).items()}
+    target = GC.train_target().to(dev)
+    ctx = hipddsp.context_for(dev)
+    errs = {}
+    for mode in (hipddsp.MATH_FP32, hipddsp.MATH_SPLIT_BF16):
+        model, cfg = synthetic.build_model("CombSub", seed=GC.TRAIN_WEIGHT_SEED, device=dev)
+        model.train()
+        crit = RSSLoss(256, 2048, 4, device=dev)
+        crit.set_scales([int(v) for v in z["scales"][0]])
+        ctx.set_math(mode)
+        try:
+            sig = model(batch["units"], batch["f0"], batch["volume"], batch["spk_id"], infer=False, noise=batch["noise"])[0]
+            loss = crit(sig, target)
+            loss.backward()
+        finally:
+            ctx.set_math(hipddsp.MATH_SPLIT_BF16)
+        assert abs(float(loss) - z["losses"][0]) < 2e-4 * z["losses"][0]
+        gn = np.array([float(p.grad.norm()) for _, p in model.named_parameters()])
+        errs[mode] = np.abs(gn / np.maximum(z["gradnorm0"], 1e-12) - 1)[z["gradnorm0"] > 1e-6].max()
+    assert errs[hipddsp.MATH_FP32] < 2e-2, errs
+    assert errs[hipddsp.MATH_SPLIT_BF16] < 5e-2, errs
+
+
+def test_grad_bucket_two_backward_passes_accumulate(dev, lib_path):
+    """the control network's direct write into the bucket is a one-shot token armed by `GradBucket.zero()`.  Two
+    backward passes before the optimizer step (micro-batches) must SUM, as they do without a bucket."""
+    import training
+    from ddsp.loss import RSSLoss
+    B, Fr = 2, 40
+    halves = []
+    for s in (191, 192):
+        d = {k: v.to(dev) for k, v in synthetic.make_inputs(s, B, Fr).items()}
+        d["audio"] = (0.1 * torch.randn(B, Fr * 512, generator=torch.Generator().manual_seed(s))).to(dev)
+        halves.append(d)
+    grads = []
+    for use_bucket in (False, True):
+        model, cfg = synthetic.build_model("CombSub", seed=33, device=dev)
+        model.train()
+        crit = RSSLoss(256, 2048, 4, device=dev)
+        crit.set_scales([300, 777, 1531, 2047])
+        bucket = training.GradBucket(model.parameters(), model) if use_bucket else None
+        if bucket is not None:
+            bucket.zero()
+        for d in halves:
+            sig = model(d["units"], d["f0"], d["volume"], d["spk_id"], infer=False, noise=d["noise"])[0]
+            crit(sig, d["audio"]).backward()
+        grads.append([p.grad.detach().clone() for p in model.parameters()])
+    for a, b in zip(*grads):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-9), float((a - b).abs().max())
+    assert any(float(g.abs().sum()) > 0 for g in grads[1])
