@@ -258,6 +258,7 @@ def test_train_step_bench_batch_against_autograd(dev, lib_path):
         sig_t = model(d["units"], d["f0"], d["volume"], d["spk_id"], infer=False, noise=d["noise"])[0]
         e_t = float((sig_t.cpu() - sig_to).double().pow(2).mean().sqrt())
         assert e_t < 1e-4, (e_t, float(sig_to.double().pow(2).mean().sqrt()))          # the north_star gate, train mode
+        crit.set_scales(scales)                                   # (a pinned draw serves ONE call)
         loss_t = crit(sig_t, target.to(dev))
     assert abs(float(loss_t) - float(loss_to)) < 5e-5 * float(loss_to), (float(loss_t), float(loss_to))
     # the loss kernel at full size, at the oracle's signal
@@ -346,11 +347,11 @@ def test_grad_bucket_two_backward_passes_accumulate(dev, lib_path):
         model, cfg = synthetic.build_model("CombSub", seed=33, device=dev)
         model.train()
         crit = RSSLoss(256, 2048, 4, device=dev)
-        crit.set_scales([300, 777, 1531, 2047])
         bucket = training.GradBucket(model.parameters(), model) if use_bucket else None
         if bucket is not None:
             bucket.zero()
         for d in halves:
+            crit.set_scales([300, 777, 1531, 2047])               # (a pinned draw serves one call)
             sig = model(d["units"], d["f0"], d["volume"], d["spk_id"], infer=False, noise=d["noise"])[0]
             crit(sig, d["audio"]).backward()
         grads.append([p.grad.detach().clone() for p in model.parameters()])
