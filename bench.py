@@ -97,6 +97,11 @@ def measured_traffic(family, split=True):
         # kernel template also runs the prenet convs and the filter-synthesis DFTs, which are other families
         elif family != "u2c_gemm_linear":
             return None          # no PMC pass committed for this family
+        elif "kernel_ws<" in k:                        # the head (wave-specialised kernel): split-bf16 products only
+            if not split:
+                continue
+            tot += v["hbm_bytes_per_launch"] * v["launches_sampled"]
+            n += v["launches_sampled"]
         elif "kernel_dma" in k and any(t in k for t in ("EpiSplit3", "EpiGlu", "EpiResidual",
                                                         "kernel_dma<128, 128, gemm::EpiStore")):
             m = re.search(r", (\d+)>\(", k)

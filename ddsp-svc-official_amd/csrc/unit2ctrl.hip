@@ -809,6 +809,68 @@ __global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ x
     }
 }
 
+// The same convolution + SiLU for the inference forward at large batches, two ADJACENT channels per thread (round 3).
+// The one-channel kernel above is bound by vector-instruction issue, not by memory (r02_e_pmc_sq_synth.txt: 2300 instructions
+// per wave for 32 outputs of 64 channels, VALU 0.62 at ~4 cycles per instruction, 24.5 us for 45 MB): 31 multiply-adds per
+// output are its floor.  With a channel PAIR per thread the pair is the packed operand - taps, window and accumulator of the two
+// channels sit in adjacent registers as they come from memory (8-byte loads), so every `v_pk_fma_f32` does two outputs and no
+// register re-alignment is needed (the packed form ACROSS frames of round 2 needed moves for every other window position).
+// Sigmoid by v_exp_f32 / v_rcp_f32 (~2 ulp).  Split output: the four lanes of a channel octet exchange their bf16 pairs so
+// that each stores 8 contiguous bytes of the (8 hi | 8 lo) group.
+typedef float f32x2_dw __attribute__((ext_vector_type(2)));
+template <int RUN>
+__global__ void __launch_bounds__(256, 3) dwconv_pair_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, int B, int Fr,
+                                                          float* __restrict__ out, int left, int split) {
+    const int cp = blockIdx.x * 256 + threadIdx.x;      // channel pair (INNER / 2 = 256 pairs: one block in x)
+    const int c = 2 * cp;
+    const int runs = (Fr + RUN - 1) / RUN;
+    const int b = blockIdx.y / runs, f0 = (blockIdx.y % runs) * RUN;
+    f32x2_dw wt[DWK];
+#pragma unroll
+    for (int t = 0; t < DWK; ++t) wt[t] = *(const f32x2_dw*)(w + t * INNER + c);      // [tap][channel] copy
+    const float* xb = x + ((int64_t)b * Fr) * INNER + c;
+    f32x2_dw win[RUN + DWK - 1];
+#pragma unroll
+    for (int i = 0; i < RUN + DWK - 1; ++i) {
+        const int f = f0 + i - left;
+        win[i] = (f >= 0 && f < Fr) ? *(const f32x2_dw*)(xb + (int64_t)f * INNER) : f32x2_dw{0.f, 0.f};
+    }
+    const f32x2_dw bi = *(const f32x2_dw*)(bias + c);
+    const int q = threadIdx.x & 3;                       // position in the channel octet
+#pragma unroll
+    for (int o = 0; o < RUN; ++o) {
+        f32x2_dw acc = bi;
+#pragma unroll
+        for (int t = 0; t < DWK; ++t) acc = __builtin_elementwise_fma(wt[t], win[o + t], acc);
+        f32x2_dw y;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            y[e] = acc[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * acc[e]));
+        const bool ok = f0 + o < Fr;
+        float* dst = out + ((int64_t)b * Fr + f0 + o) * INNER + c;
+        if (split) {
+            // octet = lanes 4g..4g+3 (channels 8g..8g+7): lane q holds bf16 pairs h_q, l_q; the group is [h0 h1 h2 h3 | l0 l1 l2 l3]
+            typedef __bf16 bf16x2_dw __attribute__((ext_vector_type(2)));
+            const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(y, bf16x2_dw));
+            const f32x2_dw rem = y - f32x2_dw{__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u)};
+            const uint32_t l = __builtin_bit_cast(uint32_t, __builtin_convertvector(rem, bf16x2_dw));
+            // lane 0 stores (h0, h1), lane 1 (h2, h3), lane 2 (l0, l1), lane 3 (l2, l3)
+            const int lane = threadIdx.x & 63, base = lane & ~3;
+            const int s0 = base + 2 * (q & 1), s1 = s0 + 1;
+            const uint32_t h0 = (uint32_t)__shfl((int)h, s0, 64), h1 = (uint32_t)__shfl((int)h, s1, 64);
+            const uint32_t l0 = (uint32_t)__shfl((int)l, s0, 64), l1 = (uint32_t)__shfl((int)l, s1, 64);
+            if (ok) {
+                uint32_t* g = (uint32_t*)(out + ((int64_t)b * Fr + f0 + o) * INNER + (c & ~7)) + 2 * q;
+                g[0] = q < 2 ? h0 : l0;
+                g[1] = q < 2 ? h1 : l1;
+            }
+        } else if (ok) {
+            *(f32x2_dw*)dst = y;
+        }
+    }
+}
+
 // =====================================================================================================
 // Backward kernels (training).  Every contraction is again a GEMM on the fp32 matrix pipe (dX = dY W,
 // dW = dY^T X as split-K batches + a reduction); the kernels below are the row-wise adjoints around them.
@@ -1627,6 +1689,11 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         return (ws_mask & layer_bit) && presplit_w && g.math == DDSP_MATH_SPLIT_BF16 && gemm::ws_ok(g) && g.N % 128 == 0 &&
                (int64_t)((g.M + 127) / 128) * (g.N / 128) >= 512;
     };
+    static int dw_pair = -1;   // DDSP_DW_PAIR=0: the one-channel depthwise kernel at every size (measurement aid)
+    if (dw_pair < 0) {
+        const char* e = getenv("DDSP_DW_PAIR");
+        dw_pair = e ? atoi(e) : 1;
+    }
     bool conv_split = false;
     // ---- prenet: conv k3 -> GroupNorm(4) -> LeakyReLU -> conv k3 ----
     {
@@ -1808,7 +1875,14 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
                  hipLaunchKernelGGL(glu_kernel, dim3(grid_for(M * (INNER / 4))), dim3(256), 0, st, b.g1, M, b.glu));
         }
         PROF(PF_U2C_ROWWISE, 2.0 * M * INNER * DWK, 8.0 * M * INNER,
-             if (B * ((Fr + DW_RUN - 1) / DW_RUN) >= 64)
+             if (!b.pre && dw_pair == 1 && B * ((Fr + 15) / 16) >= 512)
+                 // inference, large batches: two channels per thread on packed multiply-adds, runs of 16 frames
+                 hipLaunchKernelGGL((dwconv_pair_kernel<16>), dim3(1, (unsigned)(B * ((Fr + 15) / 16))), dim3(256), 0, st,
+                                    b.glu, bf.wdw + (size_t)l * DWK * INNER, L.cm_dw_b, (int)B, (int)Fr, b.dwo, w.causal ? DWK - 1 : DWK / 2, asplit);
+             else if (!b.pre && dw_pair == 2 && B * ((Fr + 13) / 14) >= 512)
+                 hipLaunchKernelGGL((dwconv_pair_kernel<14>), dim3(1, (unsigned)(B * ((Fr + 13) / 14))), dim3(256), 0, st,
+                                    b.glu, bf.wdw + (size_t)l * DWK * INNER, L.cm_dw_b, (int)B, (int)Fr, b.dwo, w.causal ? DWK - 1 : DWK / 2, asplit);
+             else if (B * ((Fr + DW_RUN - 1) / DW_RUN) >= 64)
                  hipLaunchKernelGGL((dwconv_kernel<true, false>), dim3(INNER / 256, (unsigned)(B * ((Fr + DW_RUN - 1) / DW_RUN))),
                                     dim3(256), 0, st, b.glu, bf.wdw + (size_t)l * DWK * INNER, L.cm_dw_b, (int)B, (int)Fr, b.dwo, b.pre, 1, INNER, w.causal ? DWK - 1 : DWK / 2, asplit);
              else   // a few utterances (the real-time block): runs of 8 frames, four times as many workgroups
