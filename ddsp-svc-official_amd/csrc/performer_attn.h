@@ -20,6 +20,10 @@ void performer_kv_bf16(hipStream_t st, const float* k, const float* v, const voi
                        int ablate = 0);
 void performer_q_bf16(hipStream_t st, const float* q, const void* p3, const float* ctxS, const float* ks, int B, int Fr,
                       float* attn, int ablate = 0, int out_split = 0);   // out_split: attn as bf16 hi/lo groups (gemm A_split)
+// both sides in one kernel (round 3): ctx and ks stay in the LDS of the (utterance, head)'s workgroup
+bool performer_fused_enabled();
+hipError_t performer_fused_bf16(hipStream_t st, const float* q, const float* k, const float* v, const void* p3, int B, int Fr,
+                                float* attn, int out_split = 0);
 // ctxT[(b*8+h)][e][j] (64 x 272: the context matrix TRANSPOSED, pad features zero) and ks[(b*8+h)] (PERFORMER_KS_STRIDE floats each) from k, v (B*Fr, 512) and P (266, 64)
 void performer_kv(hipStream_t st, const float* k, const float* v, const float* P, int B, int Fr, float* ctxT, float* ks);
 // attn (B*Fr, 512) from q (B*Fr, 512), P, ctxT, ks

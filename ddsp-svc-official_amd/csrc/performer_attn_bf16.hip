@@ -25,6 +25,9 @@
 // bytes per MAC and the instruction count, and the matrix time is no longer what bounds these kernels).
 #include "performer_attn.h"
 
+#include <atomic>
+#include <stdlib.h>
+
 namespace {
 
 constexpr int H = 8, DH = 64, INNER = 512, NF = 266;
@@ -510,6 +513,422 @@ __global__ void __launch_bounds__(64 * QW, 3) performer_q_bf16_kernel(const floa
         }
 }
 
+
+// ---- both sides in ONE kernel (round 3) -------------------------------------------------------------------------------------
+// One workgroup of 12 wavefronts per (utterance, head) runs the key side and then the query side; the context matrix (288 x 64
+// as bf16 hi / lo pieces, 72 KiB) and the key sums never leave the LDS - the round-2 pair wrote 38 MB of ctx pieces per layer to
+// HBM and streamed them back (86.5 MB per launch each, 0.05 of the bf16 peak), and paid a kernel boundary in between.
+//   key phase    = performer_kv_bf16_kernel: 9 product waves (one per 32-feature tile) + 3 staging waves per 32-frame tile;
+//                  its results go to LDS regions C (ctx pieces, in the query side's operand order) and S (ks, eps parts).
+//   query phase  : passes of up to 6 frame tiles; TWO waves per frame tile, one taking the even, one the odd feature tiles
+//                  (5 rounds; each round stages the projection pieces of its two feature tiles by global_load_lds), each with
+//                  its own running row maximum; the odd wave hands (m, D, out^T) to the even one through the LDS, which
+//                  rescales both to the common maximum - the maximum is the exact row maximum over all 266 features, as the
+//                  reference's `softmax_kernel` needs it for the weight of its eps term (pcmer.py:140-141).
+// LDS (16-byte units): A [0, 3072) key-phase stages / query-phase projection stages (2 x 24 pieces) and the hand-over;
+// C [3072, 7680) ctx pieces; S [7680, 7900): ks[288] | cpart[9][64] | kpart[9..] floats.
+constexpr int F_A = 0, F_C = 3072, F_S = 7680, F_UNITS = 7900;
+constexpr int F_QBUF = 1536;                    // one query-phase stage: 24 one-KiB pieces
+constexpr int FQ_TILES = 6;                     // frame tiles per query pass (two waves each)
+static_assert(2 * K_STAGE <= F_C && 2 * F_QBUF <= F_C, "region A holds either phase's stages");
+
+__global__ void __launch_bounds__(64 * (KG + KS_WAVES), 3) performer_fused_bf16_kernel(const float* __restrict__ q,
+                                                                                 const float* __restrict__ k,
+                                                                                 const float* __restrict__ v,
+                                                                                 const uint4* __restrict__ p3, int Fr,
+                                                                                 float* __restrict__ attn, int out_split) {
+    extern __shared__ __attribute__((aligned(1024))) uint4 lds[];
+    float* const sks = (float*)(lds + F_S);                   // ks[288] | cpart[9][64] | kpart[9]
+    constexpr int S_CPART = 288, S_KPART = 288 + NJT * DH;
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int n_ft = (Fr + 31) / 32;
+
+    // ============================== key phase ==============================
+    if (wave >= KG) {
+        // staging waves: see performer_kv_bf16_kernel
+        const int ws = wave - KG;
+        const float* kb = k + ((int64_t)b * Fr) * INNER + h * DH;
+        const float* vb = v + ((int64_t)b * Fr) * INNER + h * DH;
+        if (ws == 0) lds[F_A + (lane >> 5) * K_STAGE + K_KD + 32 + l31] = uint4{0u, 0u, 0u, 0u};
+        auto load_round = [&](int r, int ft, float (&x)[8]) __attribute__((always_inline)) {
+            if (r < 4) {
+                const int fi = 8 * r + (lane & 7), f = 32 * ft + fi;
+                const float* src = kb + (int64_t)(f < Fr ? f : Fr - 1) * INNER + 8 * (lane >> 3);
+                const f32x4_t a0 = *(const f32x4_t*)src, a1 = *(const f32x4_t*)(src + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = f < Fr ? (e < 4 ? a0[e & 3] : a1[e & 3]) : 0.f;
+            } else if (r < 8) {
+                const int o = r - 4;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int f = 32 * ft + 16 * (o >> 1) + 4 * (o & 1) + (e & 3) + 8 * (e >> 2);
+                    x[e] = f < Fr ? vb[(int64_t)f * INNER + lane] : 0.f;
+                }
+            }
+        };
+        auto store_round = [&](int r, int ft, const float (&x)[8]) __attribute__((always_inline)) {
+            uint4* st = lds + F_A + (ft & 1) * K_STAGE;
+            if (r < 4) {
+                const int fi = 8 * r + (lane & 7), c8 = lane >> 3;
+                u32x4 pc[3];
+                split<3>(x, pc);
+#pragma unroll
+                for (int qq = 0; qq < 3; ++qq)
+                    st[K_KP + (((c8 >> 1) * 3 + qq) * 2 + (c8 & 1)) * 32 + fi] = __builtin_bit_cast(uint4, pc[qq]);
+                float ss = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss = fmaf(x[e], x[e], ss);
+                ss += __shfl_xor(ss, 8, 64);
+                ss += __shfl_xor(ss, 16, 64);
+                ss += __shfl_xor(ss, 32, 64);
+                if (c8 == 0) {
+                    const float d[8] = {NEG_HALF * ss, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    u32x4 dp[3];
+                    split<3>(d, dp);
+                    const u32x4 o_ = {(dp[0][0] & 0xffffu) | (dp[1][0] << 16), dp[2][0] & 0xffffu, 0u, 0u};
+                    st[K_KD + fi] = __builtin_bit_cast(uint4, o_);
+                }
+            } else if (r < 8) {
+                const int o = r - 4;
+                u32x4 pc[2];
+                split<2>(x, pc);
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq)
+                    st[K_VP + ((((o >> 1) * 2 + qq) * 2 + lh) * 2 + (o & 1)) * 32 + l31] = __builtin_bit_cast(uint4, pc[qq]);
+            }
+        };
+        float x[3][8];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) load_round(ws + 3 * i, 0, x[i]);
+#pragma unroll 1
+        for (int ft = 0; ft < n_ft; ++ft) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) store_round(ws + 3 * i, ft, x[i]);
+            if (ft + 1 < n_ft) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) load_round(ws + 3 * i, ft + 1, x[i]);
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+    } else {
+        const int jt = wave;
+        bf16x8 pb[4][3];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+            for (int qq = 0; qq < 3; ++qq)
+                pb[s2][qq] = __builtin_bit_cast(bf16x8, p3[(((jt * 4 + s2) * 3 + qq) * 2 + lh) * 32 + l31]);
+        u32x4 ones = {0u, 0u, 0u, 0u};
+        if (lh == 0) {
+            ones[0] = 0x3f803f80u;
+            ones[1] = 0x00003f80u;
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+        float ksum = 0.f;
+        const float c_init = 32 * jt + l31 < NF ? KOFF : MASKED;
+        __syncthreads();                   // tile 0 is staged
+#pragma unroll 1
+        for (int ft = 0; ft < n_ft; ++ft) {
+            const uint4* st = lds + F_A + (ft & 1) * K_STAGE;
+            f32x16 S;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[r] = c_init;
+            if (ft == n_ft - 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (32 * ft + (r & 3) + 8 * (r >> 2) + 4 * lh >= Fr) S[r] = MASKED;
+            }
+            bf16x8 a[2][3];
+            const uint4* kp = st + K_KP + lh * 32 + l31;
+#pragma unroll
+            for (int qq = 0; qq < 3; ++qq) a[0][qq] = __builtin_bit_cast(bf16x8, kp[qq * 64]);
+            const bf16x8 ad = __builtin_bit_cast(bf16x8, st[K_KD + lh * 32 + l31]);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                if (s2 + 1 < 4) {
+#pragma unroll
+                    for (int qq = 0; qq < 3; ++qq) a[(s2 + 1) & 1][qq] = __builtin_bit_cast(bf16x8, kp[((s2 + 1) * 3 + qq) * 64]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8(&c)[3] = a[s2 & 1];
+                S = MFMA_BF16(c[2], pb[s2][0], S);
+                S = MFMA_BF16(c[0], pb[s2][2], S);
+                S = MFMA_BF16(c[1], pb[s2][1], S);
+                S = MFMA_BF16(c[1], pb[s2][0], S);
+                S = MFMA_BF16(c[0], pb[s2][1], S);
+                S = MFMA_BF16(c[0], pb[s2][0], S);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            S = MFMA_BF16(ad, as_bf(ones), S);
+            const uint4* vp = st + K_VP + lh * 32 + l31;
+            bf16x8 vf[2][2];
+            vf[0][0] = __builtin_bit_cast(bf16x8, vp[0]);
+            vf[0][1] = __builtin_bit_cast(bf16x8, vp[2 * 64]);
+            __builtin_amdgcn_sched_barrier(0);
+            float kf[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                kf[r] = __builtin_amdgcn_exp2f(S[r]);
+                ksum += kf[r];
+            }
+#pragma unroll
+            for (int step = 0; step < 2; ++step) {
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = kf[8 * step + e];
+                u32x4 ap[2];
+                split<2>(x, ap);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const int pr = step * 2 + ct;
+                    if (pr + 1 < 4) {
+                        const int ns = (pr + 1) >> 1, nc = (pr + 1) & 1;
+                        vf[(pr + 1) & 1][0] = __builtin_bit_cast(bf16x8, vp[(((ns * 2 + 0) * 2 + nc) * 2) * 32]);
+                        vf[(pr + 1) & 1][1] = __builtin_bit_cast(bf16x8, vp[(((ns * 2 + 1) * 2 + nc) * 2) * 32]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[ct] = MFMA_BF16(as_bf(ap[1]), vf[pr & 1][0], acc[ct]);
+                    acc[ct] = MFMA_BF16(as_bf(ap[0]), vf[pr & 1][1], acc[ct]);
+                    acc[ct] = MFMA_BF16(as_bf(ap[0]), vf[pr & 1][0], acc[ct]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();
+        }
+        // results stay in the LDS: ks | eps parts (region S), ctx pieces in the query side's operand order (region C)
+        ksum += __shfl_xor(ksum, 32, 64);
+        if (lh == 0) sks[32 * jt + l31] = ksum;
+        float ktot = ksum;
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) ktot += __shfl_xor(ktot, m, 64);
+        if (lane == 0) sks[S_KPART + jt] = ktot;
+        uint4* cd = lds + F_C + jt * 512;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            float cs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cs += acc[ct][r];
+            cs += __shfl_xor(cs, 32, 64);
+            if (lh == 0) sks[S_CPART + jt * DH + 32 * ct + l31] = cs;
+#pragma unroll
+            for (int step = 0; step < 2; ++step) {
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = acc[ct][8 * step + e];
+                u32x4 pc[2];
+                split<2>(x, pc);
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) cd[(((step * 2 + qq) * 2 + ct) * 2 + lh) * 32 + l31] = __builtin_bit_cast(uint4, pc[qq]);
+            }
+        }
+    }
+    __syncthreads();      // ctx, ks and the eps parts are complete; region A is free
+
+    // ============================== query phase ==============================
+    const int ftw = wave % FQ_TILES, par = wave / FQ_TILES;           // frame tile of the pass, feature-tile parity
+    constexpr int ROUNDS = (NJT + 1) / 2;
+    // stage round r: projection pieces of feature tiles 2r (pieces 0..11) and 2r + 1 (12..23), two pieces per wave
+    auto issue = [&](int r, int buf) {
+        // (r made opaque: the compiler otherwise computes the ten 64-bit source addresses of all rounds once per kernel, keeps
+        // them across the pass loop and spills them - 41 registers of scratch in the first build)
+        asm volatile("" : "+s"(r));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wave + 12 * i;
+            const int jt = 2 * r + piece / 12;
+            if (jt < NJT)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p3 + (jt * 12 + piece % 12) * 64 + lane),
+                                                 (__attribute__((address_space(3))) void*)(lds + F_A + buf * F_QBUF + piece * 64),
+                                                 16, 0, 0);
+        }
+    };
+#pragma unroll 1
+    for (int pass = 0; pass * FQ_TILES < n_ft; ++pass) {
+        const int ft = pass * FQ_TILES + ftw;
+        const int frame = 32 * ft + l31;
+        const bool frame_ok = frame < Fr;
+        issue(0, 0);
+        bf16x8 qb[4][3];
+        float ss = 0.f;
+        {
+            const float* qr = q + ((int64_t)b * Fr + (frame_ok ? frame : Fr - 1)) * INNER + h * DH + 8 * lh;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const f32x4_t a0 = *(const f32x4_t*)(qr + 16 * s2), a1 = *(const f32x4_t*)(qr + 16 * s2 + 4);
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    x[e] = frame_ok ? (e < 4 ? a0[e] : a1[e - 4]) : 0.f;
+                    ss = fmaf(x[e], x[e], ss);
+                }
+                u32x4 pc[3];
+                split<3>(x, pc);
+#pragma unroll
+                for (int pp2 = 0; pp2 < 3; ++pp2) qb[s2][pp2] = as_bf(pc[pp2]);
+            }
+        }
+        ss += __shfl_xor(ss, 32, 64);
+        const float diag2 = -NEG_HALF * ss;
+        float m_run = -3.0e38f, Dacc = 0.f;
+        f32x16 o[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+#pragma unroll 1
+        for (int r = 0; r < ROUNDS; ++r) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                  // round r has landed for every wave; the other buffer is free
+            if (r + 1 < ROUNDS) issue(r + 1, (r + 1) & 1);
+            const int jt = 2 * r + par;
+            if (jt < NJT) {
+                const uint4* st = lds + F_A + (r & 1) * F_QBUF + par * 768;
+                f32x16 S;
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) S[rr] = 0.f;
+                if (jt == NJT - 1) {
+#pragma unroll
+                    for (int rr = 0; rr < 16; ++rr)
+                        if (32 * jt + (rr & 3) + 8 * (rr >> 2) + 4 * lh >= NF) S[rr] = MASKED;
+                }
+                const uint4* pp = st + lh * 32 + l31;
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    // (one fragment set: the two other waves of the SIMD cover the LDS round trip; a second set, as in the
+                    // stand-alone query kernel, spills 10 registers here)
+                    bf16x8 c[3];
+#pragma unroll
+                    for (int pq = 0; pq < 3; ++pq) c[pq] = __builtin_bit_cast(bf16x8, pp[(s2 * 3 + pq) * 64]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    S = MFMA_BF16(c[2], qb[s2][0], S);
+                    S = MFMA_BF16(c[0], qb[s2][2], S);
+                    S = MFMA_BF16(c[1], qb[s2][1], S);
+                    S = MFMA_BF16(c[1], qb[s2][0], S);
+                    S = MFMA_BF16(c[0], qb[s2][1], S);
+                    S = MFMA_BF16(c[0], qb[s2][0], S);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const uint4* cp = lds + F_C + jt * 512 + lh * 32 + l31;
+                bf16x8 cf[2][2];
+                cf[0][0] = __builtin_bit_cast(bf16x8, cp[0]);
+                cf[0][1] = __builtin_bit_cast(bf16x8, cp[2 * 64]);
+                __builtin_amdgcn_sched_barrier(0);
+                float tmax = S[0];
+#pragma unroll
+                for (int rr = 1; rr < 16; ++rr) tmax = fmaxf(tmax, S[rr]);
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float m_new = fmaxf(m_run, tmax);
+                const float sc = __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+                const float dm = m_run + diag2;
+                if (__any(sc != 1.0f)) {
+                    Dacc *= sc;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int rr = 0; rr < 16; ++rr) o[c][rr] *= sc;
+                }
+                float u[16];
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) u[rr] = __builtin_amdgcn_exp2f(S[rr] - dm);
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4_t kv = *(const f32x4_t*)(sks + 32 * jt + 8 * g4 + 4 * lh);    // ks of the tile's features
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Dacc = fmaf(u[4 * g4 + e], kv[e], Dacc);
+                }
+#pragma unroll
+                for (int step = 0; step < 2; ++step) {
+                    float x[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = u[8 * step + e];
+                    u32x4 bp[2];
+                    split<2>(x, bp);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        const int pr = step * 2 + ct;
+                        if (pr + 1 < 4) {
+                            const int ns = (pr + 1) >> 1, nc = (pr + 1) & 1;
+                            cf[(pr + 1) & 1][0] = __builtin_bit_cast(bf16x8, cp[(((ns * 2 + 0) * 2 + nc) * 2) * 32]);
+                            cf[(pr + 1) & 1][1] = __builtin_bit_cast(bf16x8, cp[(((ns * 2 + 1) * 2 + nc) * 2) * 32]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        o[ct] = MFMA_BF16(cf[pr & 1][1], as_bf(bp[0]), o[ct]);
+                        o[ct] = MFMA_BF16(cf[pr & 1][0], as_bf(bp[1]), o[ct]);
+                        o[ct] = MFMA_BF16(cf[pr & 1][0], as_bf(bp[0]), o[ct]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+        // hand-over odd -> even wave of a frame tile through region A (free after the last round's barrier ... of the NEXT
+        // barrier: every wave has finished reading its last stage when it passes the first barrier below)
+        Dacc += __shfl_xor(Dacc, 32, 64);
+        float* xch = (float*)(lds + F_A);                     // [ftw][18][64] floats per half
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();
+            if (par == 1) {
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) xch[(ftw * 18 + rr) * 64 + lane] = o[half][rr];
+                if (half == 0) {
+                    xch[(ftw * 18 + 16) * 64 + lane] = m_run;
+                    xch[(ftw * 18 + 17) * 64 + lane] = Dacc;
+                }
+            }
+            __syncthreads();
+            if (par == 0) {
+                if (half == 0) {
+                    const float m1 = xch[(ftw * 18 + 16) * 64 + lane], D1 = xch[(ftw * 18 + 17) * 64 + lane];
+                    const float m = fmaxf(m_run, m1);
+                    const float s0 = __builtin_amdgcn_exp2f(m_run - m), s1 = __builtin_amdgcn_exp2f(m1 - m);
+                    Dacc = Dacc * s0 + D1 * s1;
+                    // keep the two scale factors for both halves in m_run (s0) and ss (s1)
+                    m_run = s0;
+                    ss = s1;
+                }
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) o[half][rr] = o[half][rr] * m_run + xch[(ftw * 18 + rr) * 64 + lane] * ss;
+            }
+        }
+        if (par == 0) {
+            // eps terms: column sums of ctx (lane = channel) and the sum of ks, from the parts of the key phase
+            float cs_lane = 0.f, ks_tot = lane < NJT ? sks[S_KPART + lane] : 0.f;
+#pragma unroll
+            for (int t = 0; t < NJT; ++t) cs_lane += sks[S_CPART + t * DH + lane];
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) ks_tot += __shfl_xor(ks_tot, m, 64);
+            const float cs_eps = EPS * cs_lane;
+            const float D = RATIO * fmaf(EPS, ks_tot, Dacc);
+            const float dinv = RATIO / (D + 1e-8f);
+            float* orow = attn + ((int64_t)b * Fr + frame) * INNER + h * DH;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int ch = 32 * ct + 8 * g4 + 4 * lh;
+                    f32x4_t res;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) res[e] = (o[ct][4 * g4 + e] + __shfl(cs_eps, ch + e, 64)) * dinv;
+                    if (out_split) {
+                        const ddsp_u32x4 sp = ddsp_split4_pair(res, lh != 0, 32);
+                        if (frame_ok) *(ddsp_u32x4*)(orow + ch) = sp;
+                    } else if (frame_ok) {
+                        *(f32x4_t*)(orow + ch) = res;
+                    }
+                }
+        }
+        __syncthreads();      // region A is free for the next pass's stages
+    }
+}
+
 }  // namespace
 
 void performer_p3(hipStream_t st, const float* P0, const float* P1, const float* P2, void* p3) {
@@ -547,6 +966,33 @@ void performer_q_bf16(hipStream_t st, const float* q, const void* p3, const floa
                        (const uint4*)ctxS, ks, Fr, n_fg, attn, out_split);
 }
 
+// DDSP_ATTN_FUSED=0: the round-2 kernel pair (measurement aid)
+bool performer_fused_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("DDSP_ATTN_FUSED");
+        on = (e && e[0] == '0') ? 0 : 1;
+    }
+    return on != 0;
+}
+
+hipError_t performer_fused_bf16(hipStream_t st, const float* q, const float* k, const float* v, const void* p3, int B, int Fr,
+                                float* attn, int out_split) {
+    static std::atomic<uint64_t> done{0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        e = hipFuncSetAttribute((const void*)performer_fused_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F_UNITS * 16);
+        if (e != hipSuccess) return e;
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(performer_fused_bf16_kernel, dim3((unsigned)(B * H)), dim3(64 * (KG + KS_WAVES)), F_UNITS * 16, st, q, k, v,
+                       (const uint4*)p3, Fr, attn, out_split);
+    return hipSuccess;
+}
+
 // ---- building block exposed for unit tests and measurements: one attention of pcmer.py:221-251 without its Linear layers ----
 extern "C" int ddsp_performer_attention(ddsp_ctx* ctx, void* stream, const float* q, const float* k, const float* v,
                                         const float* proj, int64_t B, int64_t Fr, float* out, int math) {
@@ -568,7 +1014,12 @@ extern "C" int ddsp_performer_attention(ddsp_ctx* ctx, void* stream, const float
     if ((rc = ddsp_scratch_get(ctx, n_cx * sizeof(float), (void**)&cx))) return rc;
     if ((rc = ddsp_scratch_get(ctx, n_ks * sizeof(float), (void**)&ksb))) return rc;
     if ((rc = ddsp_scratch_get(ctx, PERFORMER_P3_BYTES, &p3))) return rc;
-    if (math == DDSP_MATH_SPLIT_BF16) {
+    if (math == DDSP_MATH_SPLIT_BF16 && performer_fused_enabled() && ablate == 0) {
+        performer_p3(st, proj, nullptr, nullptr, p3);
+        ddsp_prof_begin(ctx, st, PF_U2C_GEMM_CTX);
+        DDSP_HIP(ctx, performer_fused_bf16(st, q, k, v, p3, (int)B, (int)Fr, out, 0));
+        ddsp_prof_end(ctx, st, 8.0 * B * Fr * H * NF * DH, 4.0 * B * Fr * 4 * INNER);
+    } else if (math == DDSP_MATH_SPLIT_BF16) {
         performer_p3(st, proj, nullptr, nullptr, p3);
         ddsp_prof_begin(ctx, st, PF_U2C_GEMM_CTX);
         performer_kv_bf16(st, k, v, p3, (int)B, (int)Fr, cx, ksb, ablate);

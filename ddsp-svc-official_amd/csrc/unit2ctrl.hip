@@ -1774,10 +1774,16 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
             // inference, split-bf16 products, enough (utterance, head) pairs to fill the chip with one workgroup each:
             // the LDS-staged bf16 kernels (performer_attn_bf16.hip); the output is written as the out-projection's A operand
             void* p3 = (char*)bf.p3 + (size_t)l * PERFORMER_P3_BYTES;
-            PROF(PF_U2C_GEMM_CTX, 4.0 * M8 * NF * DH, 4.0 * M * 2 * INNER,
-                 performer_kv_bf16(st, b.k, b.v, p3, (int)B, (int)Fr, b.cx, b.ks));
-            PROF(PF_U2C_GEMM_ATTNOUT, 4.0 * M8 * NF * DH, 4.0 * M * 2 * INNER,
-                 performer_q_bf16(st, b.q, p3, b.cx, b.ks, (int)B, (int)Fr, b.attn, 0, asplit));
+            if (performer_fused_enabled()) {
+                // both sides in one kernel per (utterance, head): ctx and ks stay in its LDS (round 3)
+                PROF(PF_U2C_GEMM_CTX, 8.0 * M8 * NF * DH, 4.0 * M * 4 * INNER,
+                     DDSP_HIP(ctx, performer_fused_bf16(st, b.q, b.k, b.v, p3, (int)B, (int)Fr, b.attn, asplit)));
+            } else {
+                PROF(PF_U2C_GEMM_CTX, 4.0 * M8 * NF * DH, 4.0 * M * 2 * INNER,
+                     performer_kv_bf16(st, b.k, b.v, p3, (int)B, (int)Fr, b.cx, b.ks));
+                PROF(PF_U2C_GEMM_ATTNOUT, 4.0 * M8 * NF * DH, 4.0 * M * 2 * INNER,
+                     performer_q_bf16(st, b.q, p3, b.cx, b.ks, (int)B, (int)Fr, b.attn, 0, asplit));
+            }
         } else if (w.causal) {
             // causal mode: feature maps through the GEMM + row kernels of the training path (q', k' stay in the arena for the
             // backward pass), then the sequential causal attention kernel
