@@ -54,9 +54,9 @@ SPLIT_ARITH = {"ltv_fir": "split-bf16: 3 bf16 MFMAs per fp32 product, fp32 accum
                "u2c_gemm_attnout": "split-bf16, fp32 accumulation: q P^T from three bf16 pieces per operand (6 MFMAs per fp32 "
                                    "product), q' ctx from two (3 MFMAs): 4.5 on average"}
 KERNEL_LABEL = {   # (default leg: split-bf16 products, FP32 leg)
-    "u2c_gemm_ctx": ("performer_kv_bf16_kernel (one workgroup per (utterance, head): key feature map + k'^T v context, "
-                     "v_mfma_f32_32x32x16_bf16, operands converted once per workgroup into LDS images in MFMA order; three "
-                     "launches per step)",
+    "u2c_gemm_ctx": ("performer_fused_bf16_kernel (one workgroup of 12 waves per (utterance, head): key feature map + k'^T v "
+                     "context, then query feature map + q' ctx / (q' ks) with ctx and ks kept in the LDS; "
+                     "v_mfma_f32_32x32x16_bf16; three launches per step)",
                      "performer_kv_kernel (fused key feature map + k'^T v context, fp32 MFMA 16x16x4, one wavefront per "
                      "(utterance, head, feature tile); three launches per step)"),
     "u2c_gemm_attnout": ("performer_q_bf16_kernel (one workgroup per (utterance, head): query feature map + q' ctx / (q' ks), "

@@ -1000,6 +1000,7 @@ extern "C" int ddsp_performer_attention(ddsp_ctx* ctx, void* stream, const float
     DDSP_REQUIRE(ctx, B >= 1 && B <= 4096 && Fr >= 1 && B * Fr < (1 << 26), "ddsp_performer_attention: bad shape");
     // (math = 100 + ablation mask: measurement aid of tools/attn_ablate.py, results are meaningless)
     const int ablate = math >= 100 ? math - 100 : 0;
+    const bool want_pair = math >= 100;      // 100 + mask: the round-2 kernel pair (mask 0: nothing switched off)
     if (math >= 100) math = DDSP_MATH_SPLIT_BF16;
     DDSP_REQUIRE(ctx, math == DDSP_MATH_FP32 || math == DDSP_MATH_SPLIT_BF16, "ddsp_performer_attention: unknown math");
     hipStream_t st = (hipStream_t)stream;
@@ -1014,7 +1015,7 @@ extern "C" int ddsp_performer_attention(ddsp_ctx* ctx, void* stream, const float
     if ((rc = ddsp_scratch_get(ctx, n_cx * sizeof(float), (void**)&cx))) return rc;
     if ((rc = ddsp_scratch_get(ctx, n_ks * sizeof(float), (void**)&ksb))) return rc;
     if ((rc = ddsp_scratch_get(ctx, PERFORMER_P3_BYTES, &p3))) return rc;
-    if (math == DDSP_MATH_SPLIT_BF16 && performer_fused_enabled() && ablate == 0) {
+    if (math == DDSP_MATH_SPLIT_BF16 && performer_fused_enabled() && !want_pair) {
         performer_p3(st, proj, nullptr, nullptr, p3);
         ddsp_prof_begin(ctx, st, PF_U2C_GEMM_CTX);
         DDSP_HIP(ctx, performer_fused_bf16(st, q, k, v, p3, (int)B, (int)Fr, out, 0));

@@ -39,7 +39,9 @@ def make(seed, B, Fr, scale, dev):
     return mk(scale), mk(scale), mk(1.0), P.contiguous().to(dev)
 
 
-@pytest.mark.parametrize("B,Fr", [(32, 172), (33, 87), (40, 1), (32, 33), (64, 200)])
+# (32, 400) and (32, 193): 13 and 7 frame tiles - the fused split kernel's query phase then runs 3 and 2 passes of six frame
+# tiles over the context it keeps in the LDS, the last pass with idle waves; (64, 200): 7 tiles, ragged
+@pytest.mark.parametrize("B,Fr", [(32, 172), (33, 87), (40, 1), (32, 33), (64, 200), (32, 400), (32, 193)])
 @pytest.mark.parametrize("math", [0, 3])
 def test_attention_against_fp64(ctx, dev, B, Fr, math):
     q, k, v, P = make(B + Fr, B, Fr, 1.0, dev)
@@ -85,3 +87,16 @@ def test_attention_modes_agree_in_the_model(dev, lib_path):
         c.set_math(hipddsp.MATH_SPLIT_BF16)
     a, b = outs[hipddsp.MATH_FP32], outs[hipddsp.MATH_SPLIT_BF16]
     assert float((a - b).norm() / a.norm()) < 5e-5
+
+
+def test_fused_kernel_against_the_kernel_pair(ctx, dev, monkeypatch):
+    """Round 3: key and query side of the split attention in one kernel per (utterance, head).  Its feature tiles are summed
+    in another order (even / odd tiles on two waves, combined at their common row maximum), so it equals the round-2 kernel
+    pair (ablation code 100 = the pair, nothing switched off) to rounding, not to the bit."""
+    B, Fr = 48, 172
+    q, k, v, P = make(5, B, Fr, 1.5, dev)
+    fused = ctx.performer_attention(q, k, v, P, B, Fr, math=3)
+    pair = ctx.performer_attention(q, k, v, P, B, Fr, math=100)
+    assert float((fused - pair).norm() / pair.norm()) < 2e-6
+    for _ in range(3):
+        assert torch.equal(ctx.performer_attention(q, k, v, P, B, Fr, math=3), fused)      # run-to-run bit stability
