@@ -201,9 +201,15 @@ __global__ void __launch_bounds__(256, 4) performer_kv_persist_kernel(const floa
     }
 }
 
+// PART = false: one wavefront walks all 17 feature tiles of its frame tile and stores the result.
+// PART = true (few work items: the real-time block, strong-scaled shards): the wavefront walks the feature tiles jt0 .. jt1-1
+// only and leaves (row maximum, D, out^T) relative to ITS maximum in `part` - the four waves of a workgroup share one frame
+// tile and are combined at their common maximum by performer_q_split_kernel.
+template <bool PART>
 __device__ __forceinline__ void performer_q_item(const float* __restrict__ q, const float* __restrict__ P,
                                                  const float* __restrict__ ctxT, const float* __restrict__ ks, int Fr,
-                                                 float* __restrict__ attn, int bh, int ft) {
+                                                 float* __restrict__ attn, int bh, int ft, int jt0 = 0, int jt1 = NJT,
+                                                 float* __restrict__ part = nullptr) {
     const int b = bh / H, h = bh % H;
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const int frame = 16 * ft + c;              // this lane's frame (column of S^T and of out^T)
@@ -240,9 +246,13 @@ __device__ __forceinline__ void performer_q_item(const float* __restrict__ q, co
 #pragma unroll
     for (int r = 0; r < 4; ++r) c_last[r] = 16 * (NJT - 1) + 4 * g + r < NF ? 0.f : MASKED;
     float pa[16];
-    load_quarter_row(P + c * DH + 16 * g, pa);
+    {
+        int j0 = 16 * jt0 + c;
+        j0 = j0 < NF ? j0 : NF - 1;
+        load_quarter_row(P + j0 * DH + 16 * g, pa);
+    }
 #pragma unroll 2
-    for (int jt = 0; jt < NJT; ++jt) {
+    for (int jt = jt0; jt < jt1; ++jt) {
         // operands of this tile's second product (features 16jt + 4g + t): in flight under the first product
         f32x4_t ca[4];
 #pragma unroll
@@ -281,6 +291,17 @@ __device__ __forceinline__ void performer_q_item(const float* __restrict__ q, co
 #pragma unroll
         for (int s = 0; s < 16; ++s) pa[s] = pn[s];
     }
+    if constexpr (PART) {
+        // [21][64] floats per wave: m | D partial sums (4) | out^T (16), lane-major rows
+        part[lane] = m_run;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[(1 + r) * 64 + lane] = Dacc[r];
+#pragma unroll
+        for (int et = 0; et < 4; ++et)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(5 + 4 * et + r) * 64 + lane] = o[et][r];
+        return;
+    }
     const float Dsum = group_sum((Dacc[0] + Dacc[1]) + (Dacc[2] + Dacc[3]));
     const float D = RATIO * fmaf(EPS, ks_tot, Dsum);
     const float dinv = RATIO / (D + 1e-8f);
@@ -305,7 +326,57 @@ __global__ void __launch_bounds__(256, 4) performer_q_kernel(const float* __rest
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ft = 4 * grp + wave;
     if (16 * ft >= Fr) return;
-    performer_q_item(q, P, ctxT, ks, Fr, attn, bh, ft);
+    performer_q_item<false>(q, P, ctxT, ks, Fr, attn, bh, ft);
+}
+
+// Few work items (B * 8 * ceil(Fr / 16) <= 1024: the real-time block has 48, a strong-scaled shard of 8 clips 704): one
+// wavefront per frame tile walks 17 feature tiles one after the other and the launch is a single 15 us dependency chain
+// (round 2: 3 x 15.6 us of the 0.39 ms real-time block).  Here the four waves of a workgroup share ONE frame tile and take 5 / 4
+// / 4 / 4 feature tiles each; their partial results meet in the LDS at the common row maximum (the exact maximum over all 266
+// features, as the eps term of the reference's softmax_kernel needs it), and wave w finishes channel block w.
+__global__ void __launch_bounds__(256, 4) performer_q_split_kernel(const float* __restrict__ q, const float* __restrict__ P,
+                                                                   const float* __restrict__ ctxT, const float* __restrict__ ks,
+                                                                   int Fr, int n_ft, float* __restrict__ attn) {
+    __shared__ float part[4][21 * 64];
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int ft = slot % n_ft, bh = (slot / n_ft) * 8 + xcd;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int jt0 = wave == 0 ? 0 : 1 + 4 * wave, jt1 = 5 + 4 * wave;      // 0..5 | 5..9 | 9..13 | 13..17
+    performer_q_item<true>(q, P, ctxT, ks, Fr, attn, bh, ft, jt0, jt1, part[wave]);
+    __syncthreads();
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int frame = 16 * ft + c;
+    float m = part[0][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) m = fmaxf(m, part[w][lane]);
+    float Dl = 0.f;
+    f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float sc = __builtin_amdgcn_exp2f(part[w][lane] - m);
+        float dw = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dw += part[w][(1 + r) * 64 + lane];
+            o[r] = fmaf(part[w][(5 + 4 * wave + r) * 64 + lane], sc, o[r]);      // channel block et = wave
+        }
+        Dl = fmaf(dw, sc, Dl);
+    }
+    const float* kr = ks + (int64_t)bh * KST;
+    float cs_lane = 0.f, ks_tot = lane < NJT ? kr[OFF_KPART + lane] : 0.f;
+#pragma unroll
+    for (int t = 0; t < NJT; ++t) cs_lane += kr[OFF_CPART + t * DH + lane];
+#pragma unroll
+    for (int mm = 1; mm < 64; mm <<= 1) ks_tot += __shfl_xor(ks_tot, mm, 64);
+    const float Dsum = group_sum(Dl);
+    const float D = RATIO * fmaf(EPS, ks_tot, Dsum);
+    const float dinv = RATIO / (D + 1e-8f);
+    const float cs_eps = EPS * cs_lane;
+    f32x4_t res;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) res[r] = (o[r] + __shfl(cs_eps, 16 * wave + 4 * g + r, 64)) * dinv;
+    if (frame < Fr) *(f32x4_t*)(attn + ((int64_t)b * Fr + frame) * INNER + h * DH + 4 * g + 16 * wave) = res;
 }
 
 __global__ void __launch_bounds__(256, 4) performer_q_persist_kernel(const float* __restrict__ q, const float* __restrict__ P,
@@ -324,7 +395,7 @@ __global__ void __launch_bounds__(256, 4) performer_q_persist_kernel(const float
         const int slot = s_item;
         if (slot >= n_items) return;
         const int grp = slot % n_grp, bh = (slot / n_grp) * 8 + xcd, ft = 4 * grp + wave;
-        if (ft < n_ft) performer_q_item(q, P, ctxT, ks, Fr, attn, bh, ft);
+        if (ft < n_ft) performer_q_item<false>(q, P, ctxT, ks, Fr, attn, bh, ft);
     }
 }
 
@@ -360,6 +431,16 @@ void performer_q(hipStream_t st, const float* q, const float* P, const float* ct
         (void)hipMemsetAsync(ctr + 8, 0, 32, st);
         hipLaunchKernelGGL(performer_q_persist_kernel, dim3(1024), dim3(256), 0, st, q, P, ctxT, ks, Fr, attn, ctr + 8,
                            n_grp * B, n_ft);
+        return;
+    }
+    const int n_ft = (Fr + 15) / 16;
+    static int split_max = -1;      // DDSP_ATTN_QSPLIT_MAX: work items up to which the feature range is split over four waves
+    if (split_max < 0) {
+        const char* e = getenv("DDSP_ATTN_QSPLIT_MAX");
+        split_max = e ? atoi(e) : 1024;
+    }
+    if ((int64_t)n_ft * B * H <= split_max) {
+        hipLaunchKernelGGL(performer_q_split_kernel, dim3((unsigned)(n_ft * B * H)), dim3(256), 0, st, q, P, ctxT, ks, Fr, n_ft, attn);
         return;
     }
     hipLaunchKernelGGL(performer_q_kernel, dim3((unsigned)(n_grp * B * H)), dim3(256), 0, st, q, P, ctxT, ks, Fr, n_grp, attn);

@@ -1589,7 +1589,15 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
     // Inference, and enough rows that the Linear layers run the 128x128 DMA tile anyway: GLU is formed inside the pw1
     // GEMM (half the store, no glu kernel).  Training keeps pw1's raw output for the backward pass; small batches keep
     // the tile shapes that suit them and the separate glu kernel.
-    bool fuse_glu = !bf.l[0].pre && (int64_t)((M + 127) / 128) * (2 * INNER / 128) >= 512;
+    // (round 3: at smaller batches too, on 64x128 tiles of 4 waves - one launch and one round trip of the 2 x 512-wide pw1
+    // output fewer per layer; DDSP_GLU_SMALL=0 restores the separate glu kernel below 8065 rows, measurement aid)
+    static int glu_small = -1;
+    if (glu_small < 0) {
+        const char* e = getenv("DDSP_GLU_SMALL");
+        glu_small = (e && e[0] == '0') ? 0 : 1;
+    }
+    const bool glu_large = !bf.l[0].pre && (int64_t)((M + 127) / 128) * (2 * INNER / 128) >= 512;
+    bool fuse_glu = !bf.l[0].pre && (glu_large || glu_small);
     for (int l = 0; l < 3; ++l)
         fuse_glu = fuse_glu && ((uintptr_t)w.layer[l].cm_pw1_w % 16) == 0;
     // Split-bf16 products at a size where every GEMM of the network runs the LDS-DMA kernel: nothing is split inside the
@@ -1606,8 +1614,13 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         const char* e = getenv("DDSP_U2C_PRESPLIT_MIN_ROWS");
         presplit_min_rows = e ? atoll(e) : 8192;
     }
-    const bool presplit = presplit_w && fuse_glu && M >= presplit_min_rows;
-    const bool attn_bf16 = !bf.l[0].pre && lin_math == DDSP_MATH_SPLIT_BF16 && B * H >= 256 && !w.causal;
+    const bool presplit = presplit_w && fuse_glu && glu_large && M >= presplit_min_rows;
+    static int64_t attn_bf16_min = -1;   // DDSP_ATTN_BF16_MIN: (utterance, head) pairs from which the split-bf16 attention runs
+    if (attn_bf16_min < 0) {
+        const char* e = getenv("DDSP_ATTN_BF16_MIN");
+        attn_bf16_min = e ? atoll(e) : 256;
+    }
+    const bool attn_bf16 = !bf.l[0].pre && lin_math == DDSP_MATH_SPLIT_BF16 && B * H >= attn_bf16_min && !w.causal;
     const int asplit = presplit ? 1 : 0;
     // A handful of rows (the real-time block: 87): the N = 256, K = 512 residual GEMMs (out-projection, pw2) would run on 8
     // workgroups walking 16 k-steps each.  Their K range is cut over KS_SPLITS workgroups per tile instead (32-96 workgroups,
@@ -1865,9 +1878,12 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
             if (use_ws(g, 2) && ew.vec_ok()) {
                 PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * 2 * INNER * D, 4.0 * M * (D + INNER),
                      DDSP_HIP(ctx, (gemm::ws_go<128, 128, gemm::WsGlu, 4>(st, g, ew))));
-            } else {
+            } else if (glu_large) {
                 PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * 2 * INNER * D, 4.0 * M * (D + INNER),
                      (gemm::dma_go<128, 128, EpiGlu, 2>(st, g, 1, e)));
+            } else {
+                PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * 2 * INNER * D, 4.0 * M * (D + INNER),
+                     (gemm::dma_go<64, 128, EpiGlu, 3, 4>(st, g, 1, e)));
             }
         } else {
             {

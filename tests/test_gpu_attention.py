@@ -41,7 +41,10 @@ def make(seed, B, Fr, scale, dev):
 
 # (32, 400) and (32, 193): 13 and 7 frame tiles - the fused split kernel's query phase then runs 3 and 2 passes of six frame
 # tiles over the context it keeps in the LDS, the last pass with idle waves; (64, 200): 7 tiles, ragged
-@pytest.mark.parametrize("B,Fr", [(32, 172), (33, 87), (40, 1), (32, 33), (64, 200), (32, 400), (32, 193)])
+# (1, 87), (8, 172), (2, 33), (3, 1): few work items - the fp32 query kernel then splits the feature range over the four waves
+# of a workgroup (performer_q_split_kernel) and combines them at their common row maximum
+@pytest.mark.parametrize("B,Fr", [(32, 172), (33, 87), (40, 1), (32, 33), (64, 200), (32, 400), (32, 193), (1, 87), (8, 172),
+                                  (2, 33), (3, 1)])
 @pytest.mark.parametrize("math", [0, 3])
 def test_attention_against_fp64(ctx, dev, B, Fr, math):
     q, k, v, P = make(B + Fr, B, Fr, 1.0, dev)

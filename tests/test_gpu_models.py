@@ -28,10 +28,10 @@ def _to(d, dev):
 
 
 def test_unit2ctrl_large_batch_fused_glu_matches_oracle(dev, lib_path):
-    """From 8065 rows on, inference forms the conformer's GLU inside the pw1 GEMM (gated-pair epilogue on re-ordered
-    weights, unit2ctrl.hip).  The small parity cases never reach that path, so this one does: B*Fr = 8256 rows against
-    the oracle at the same tolerances, plus a check (launch counts of the row-kernel family) that the fused path is
-    the one that ran."""
+    """Inference forms the conformer's GLU inside the pw1 GEMM (gated-pair epilogue on re-ordered weights, unit2ctrl.hip):
+    from 8065 rows on with 128x128 tiles (and pre-split activations), below with 64x128 tiles.  B*Fr = 8256 rows against
+    the oracle at the same tolerances as the small cases, plus a check (launch counts of the row-kernel family) that the
+    fused path is the one that ran at both sizes."""
     import hipddsp
     model, cfg = synthetic.build_model("CombSub", seed=99)
     sd = {k[len("unit2ctrl."):]: v for k, v in model.state_dict().items() if k.startswith("unit2ctrl.")}
@@ -54,7 +54,8 @@ def test_unit2ctrl_large_batch_fused_glu_matches_oracle(dev, lib_path):
 
     got, launches_big = run(B)
     small, launches_small = run(2)
-    assert launches_big == launches_small - 3, (launches_big, launches_small)   # three glu kernels fewer
+    # (round 3: small batches form the GLU inside the pw1 GEMM too, on 64x128 tiles - no separate glu kernel at any size)
+    assert launches_big == launches_small, (launches_big, launches_small)
     assert got.shape == want.shape
     assert (got - want).abs().max() < 2e-4
     assert rms(got - want) < 2e-5
