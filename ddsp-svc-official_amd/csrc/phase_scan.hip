@@ -157,9 +157,31 @@ __global__ void __launch_bounds__(256) frame_scan_kernel(const float* __restrict
                 if (j == 0) out.phase_frames[fidx] = ph;
                 float c = 0.f;
                 if (out.comb) {
-                    float x = __fdiv_rn(__fmul_rn(srf, r), __fadd_rn(fval[i], 1e-3f));
-                    float p = __fmul_rn(pi_f, x);
-                    c = (x == 0.0f) ? 1.0f : __fdiv_rn(sinf(p), p);
+                    // x = sr * rot / (f0 + 1e-3), comb = sin(pi x) / (pi x) (vocoder.py:539).  Round 3: the two IEEE
+                    // divisions and the full-range sinf were this kernel's time (VALU 1.17 in r02_e_pmc_sq_synth.txt:
+                    // ~45 of ~75 instructions per sample).  Now: quotient by v_rcp_f32 + one Newton step (<= 1 ulp);
+                    // x reduced EXACTLY to [-1, 1] (x - 2 rint(x / 2)) and folded to t in [-0.5, 0.5] with
+                    // sin(pi x) = sin(pi t); sin(pi t) by its odd polynomial to t^13 (|error| < 1e-8).  The reference takes
+                    // the sine of the ROUNDED product fl32(pi * x) - |x| reaches 340 - so the two agree to ~1e-7 in comb
+                    // (both are ~1 ulp evaluations of a value of magnitude <= 1 / (pi x)); tests hold 2e-5.
+                    const float den = __fadd_rn(fval[i], 1e-3f);
+                    const float num = __fmul_rn(srf, r);
+                    const float rc = __builtin_amdgcn_rcpf(den);
+                    float x = num * rc;
+                    x = fmaf(fmaf(-den, x, num), rc, x);
+                    const float xr = fmaf(-2.0f, rintf(0.5f * x), x);
+                    const float t = fabsf(xr) > 0.5f ? copysignf(1.0f, xr) - xr : xr;
+                    const float t2 = t * t;
+                    float pl = 0.00046630281f;                     // pi^13 / 13!, -pi^11 / 11!, ..., pi (Taylor; next term 2e-9)
+                    pl = fmaf(pl, t2, -0.0073704309f);
+                    pl = fmaf(pl, t2, 0.082145887f);
+                    pl = fmaf(pl, t2, -0.59926453f);
+                    pl = fmaf(pl, t2, 2.5501640f);
+                    pl = fmaf(pl, t2, -5.1677128f);
+                    pl = fmaf(pl, t2, 3.1415927f);
+                    const float sn = t * pl;                        // sin(pi x)
+                    const float px = pi_f * x;
+                    c = (x == 0.0f) ? 1.0f : sn * __builtin_amdgcn_rcpf(px);
                     if (comb_mode == DDSP_COMB_SINC_GATED && fval[i] <= 0.0f) c = 0.0f;
                 }
                 if constexpr (VEC8) {

@@ -1111,35 +1111,47 @@ __global__ void __launch_bounds__(256) glu_bwd_kernel(const float* __restrict__ 
     }
 }
 
-// depthwise-conv weight gradient: partial[(b, chunk)][c][t] = sum_{f in chunk} dpre[b,f,c] * x[b, f+t-15, c];
-// block = (64 channels, utterance, frame chunk)
-constexpr int DWG_CHUNKS = 4;
-__global__ void __launch_bounds__(256) dwconv_wgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ x,
-                                                           int Fr, float* __restrict__ partial, int left) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int tg = threadIdx.x >> 6;  // taps tg, tg+4, ...
-    const int b = blockIdx.y, ch = blockIdx.z;
-    const int per = (Fr + DWG_CHUNKS - 1) / DWG_CHUNKS;
-    const int fa = ch * per, fb = (fa + per < Fr) ? fa + per : Fr;
+// depthwise-conv weight gradient dW[c][t] = sum_{b, f} dpre[b,f,c] * x[b, f+t-left, c] with the forward kernel's register window:
+// one thread owns one channel for a run of DW_RUN frames, its DW_RUN upstream gradients and DW_RUN + 30 inputs stay in
+// registers and every tap is a 32-long dot product of them (round 3; the round-2 kernel re-read 8 inputs per multiply-add
+// batch through the L1 and took 79 us per layer at B = 32, memory-instruction bound).  partial[(b, run)][tap][channel]: coalesced 256-byte rows per tap; dw_wgrad_reduce_kernel sums the runs and
+// transposes to the parameter's (512, 1, 31) layout.
+__global__ void __launch_bounds__(256) dwconv_wgrad_run_kernel(const float* __restrict__ dpre, const float* __restrict__ x,
+                                                               int B, int Fr, float* __restrict__ partial, int left) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int runs = (Fr + DW_RUN - 1) / DW_RUN;
+    const int b = blockIdx.y / runs, f0 = (blockIdx.y % runs) * DW_RUN;
     const float* dp = dpre + ((int64_t)b * Fr) * INNER + c;
     const float* xp = x + ((int64_t)b * Fr) * INNER + c;
-    float acc[8];
+    float d[DW_RUN], win[DW_RUN + DWK - 1];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    for (int f = fa; f < fb; ++f) {
-        const float d = dp[(int64_t)f * INNER];
+    for (int o = 0; o < DW_RUN; ++o) d[o] = f0 + o < Fr ? dp[(int64_t)(f0 + o) * INNER] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int t = tg + 4 * i;
-            const int ff = f + t - left;   // left = DWK / 2: centred taps, DWK - 1: causal taps
-            if (t < DWK && ff >= 0 && ff < Fr) acc[i] = fmaf(d, xp[(int64_t)ff * INNER], acc[i]);
+    for (int i = 0; i < DW_RUN + DWK - 1; ++i) {
+        const int f = f0 + i - left;
+        win[i] = (f >= 0 && f < Fr) ? xp[(int64_t)f * INNER] : 0.f;
+    }
+    float* out = partial + ((int64_t)blockIdx.y * DWK) * INNER + c;
+#pragma unroll
+    for (int t = 0; t < DWK; ++t) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int o = 0; o < DW_RUN; o += 2) {
+            a0 = fmaf(d[o], win[o + t], a0);
+            a1 = fmaf(d[o + 1], win[o + 1 + t], a1);
         }
+        out[(int64_t)t * INNER] = a0 + a1;
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int t = tg + 4 * i;
-        if (t < DWK) partial[(((int64_t)b * DWG_CHUNKS + ch) * INNER + c) * DWK + t] = acc[i];
-    }
+}
+// dW[c][t] = sum_p partial[p][t][c]; block = 64 channels x 4 partial lanes
+__global__ void __launch_bounds__(256) dw_wgrad_reduce_kernel(const float* __restrict__ partial, int np, float* __restrict__ dW) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), t = blockIdx.y, zl = threadIdx.x >> 6;
+    float s0 = 0.f;
+    for (int z = zl; z < np; z += 4) s0 += partial[((int64_t)z * DWK + t) * INNER + c];
+    __shared__ float red[256];
+    red[threadIdx.x] = s0;
+    __syncthreads();
+    if (zl == 0) dW[c * DWK + t] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
 }
 
 // attention output adjoint, one wave per (frame, head) row: out = num * dinv  ->  d_num = d_out*dinv (in place),
@@ -2231,7 +2243,7 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
         dWh = a.get((size_t)NO * D);
         pk = a.get((size_t)D * 3 * (w.n_unit > D ? w.n_unit : D));
         xs = a.get((size_t)M * (w.n_unit > D ? w.n_unit : D));
-        dwpart = a.get((size_t)B * DWG_CHUNKS * INNER * DWK);
+        dwpart = a.get((size_t)B * ((Fr + DW_RUN - 1) / DW_RUN) * INNER * DWK);
         gbst = a.get((size_t)B * 4 * 2);
         w2t = a.get((size_t)D * 3 * D);
         wts = a.get((size_t)NO * D + 3 * ((size_t)2 * D * INNER + (size_t)2 * INNER * D + (size_t)3 * INNER * D));
@@ -2303,10 +2315,12 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
                               GLP(cm_pw2_b)))) return rc;
         dgrad(st, dX, D, L.cm_pw2_w, D, INNER, M, dB512, false, wt_pw2[l]);                                  // d_dwo
         hipLaunchKernelGGL(silu_bwd_kernel, dim3(grid_for(M * INNER)), dim3(256), 0, st, b.pre, dB512, M * INNER, dB512);  // d_pre
-        hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(INNER / 64, (unsigned)B, DWG_CHUNKS), dim3(256), 0, st, dB512, b.glu, (int)Fr, dwpart,
-                           w.causal ? DWK - 1 : DWK / 2);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((INNER * DWK + 63) / 64), dim3(256), 0, st, dwpart, (int)B * DWG_CHUNKS,
-                           (int64_t)INNER * DWK, GLP(cm_dw_w));
+        {
+            const int runs = (int)((Fr + DW_RUN - 1) / DW_RUN);
+            hipLaunchKernelGGL(dwconv_wgrad_run_kernel, dim3(INNER / 256, (unsigned)(B * runs)), dim3(256), 0, st, dB512, b.glu, (int)B,
+                               (int)Fr, dwpart, w.causal ? DWK - 1 : DWK / 2);
+            hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(INNER / 64, DWK), dim3(256), 0, st, dwpart, (int)B * runs, GLP(cm_dw_w));
+        }
         if ((rc = colsum(ctx, st, dB512, INNER, M, INNER, nullptr, 0, cpart, GLP(cm_dw_b)))) return rc;
         hipLaunchKernelGGL((dwconv_kernel<false, true>), dim3(INNER / 256, (unsigned)(B * ((Fr + DW_RUN - 1) / DW_RUN))),
                            dim3(256), 0, st, dB512, L.cm_dw_w, nullptr, (int)B, (int)Fr, dC512, nullptr, DWK, 1, w.causal ? 0 : DWK / 2, 0);   // d_glu (adjoint taps: left' = DWK - 1 - left)
