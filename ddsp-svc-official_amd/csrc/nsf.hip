@@ -366,6 +366,142 @@ __global__ void __launch_bounds__(256) conv_small_kernel(ConvSmallArgs g) {
     }
 }
 
+// ---- one residual pair of the 16-channel stage in ONE kernel (round 3) ------------------------------------------------------
+// nsf_hifigan/models.py ResBlock1: xt = c1_dilated(leaky_relu(x)); xt = c2(leaky_relu(xt)); x = xt + x.  As two conv_small launches
+// the stage moves four 28 MB tensors per convolution at 860 frames (activated input and residual in, raw and activated
+// output out).  Here only x is read and the result written, and c1's output never leaves the CU: a wavefront owns 64 output frames,
+// computes c1 for those frames plus c2's halo (5 tiles of 16 frames), writes it activated - and zeroed outside the signal,
+// c2 pads ITS input with zeros - into a second LDS window, and runs c2 from there.  Both weights sit in the LDS.
+struct ConvPairRawArgs {
+    const float* x;       // (T, C) raw: the window (activated while it is staged) AND the residual
+    const float *w1, *b1, *w2, *b2;
+    float* out;           // may be null
+    float* out_act;       // may be null
+    int64_t T;
+    int ktaps, dil;
+    float slope;          // of the activations in front of c1 and c2, and of out_act
+};
+typedef uint32_t ddsp_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int CP_MID = 80;          // c1 output rows per window: 64 + 2 * 5 halo rows of c2, whole 16-row tiles
+constexpr int CP_MAX_HALO = 30;     // (k - 1) / 2 * (dil + 1)
+
+__global__ void __launch_bounds__(256) conv_pair16_kernel(ConvPairRawArgs g) {
+    constexpr int C = 16, P = C + 1;
+    extern __shared__ float lds[];
+    const int h2 = (g.ktaps - 1) / 2, h1 = h2 * g.dil, halo = h1 + h2, rows = CS_TW + 2 * halo;
+    float* const wl1 = lds;                                            // [tap][ci][co]
+    float* const wl2 = lds + g.ktaps * C * C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* const win = lds + 2 * g.ktaps * C * C + wave * (rows + CP_MID) * P;   // x_act window, then the c1 output window
+    float* const mid = win + rows * P;
+    for (int i = threadIdx.x; i < g.ktaps * C * C; i += 256) {
+        const int co = i / (g.ktaps * C), r = i % (g.ktaps * C);
+        wl1[r * C + co] = g.w1[i];
+        wl2[r * C + co] = g.w2[i];
+    }
+    __syncthreads();
+    const int64_t nchunks = (g.T + CS_TW - 1) / CS_TW;
+    constexpr int NV = ((CS_TW + 2 * CP_MAX_HALO) * C / 4 + 63) / 64;
+    const int nvec = rows * C / 4;
+    f32x4 pre[NV];
+    auto load_window = [&](int64_t t0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = (lane + 64 * i) * 4;
+            const int64_t t = t0 - halo + e / C;
+            pre[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (lane + 64 * i < nvec && t >= 0 && t < g.T) pre[i] = *(const f32x4*)(g.x + t * C + e % C);
+        }
+    };
+    auto store_window = [&]() {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = (lane + 64 * i) * 4;
+            if (lane + 64 * i < nvec) {
+                float* p = win + (e / C) * P + e % C;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) p[j] = pre[i][j] > 0.f ? pre[i][j] : pre[i][j] * g.slope;
+            }
+        }
+    };
+    const int li = lane & 15, lk = lane >> 4;
+    const float bc1 = g.b1 ? g.b1[li] : 0.f, bc2 = g.b2 ? g.b2[li] : 0.f;
+    const int64_t first = (int64_t)blockIdx.x * 4 + wave, step = (int64_t)gridDim.x * 4;
+    if (first < nchunks) {
+        load_window(first * CS_TW);
+        store_window();
+    }
+    for (int64_t chunk = first; chunk < nchunks; chunk += step) {
+        const int64_t t0 = chunk * CS_TW;
+        const bool more = chunk + step < nchunks;
+        if (more) load_window((chunk + step) * CS_TW);
+        __builtin_amdgcn_wave_barrier();
+        // ---- c1 on frames t0 - h2 .. t0 - h2 + 79 (window row of output u at tap: u + h1 + (tap - h2) * dil) ----
+        {
+            f32x4 acc[5];
+#pragma unroll
+            for (int tt = 0; tt < 5; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int tap = 0; tap < g.ktaps; ++tap) {
+                const float* wr = wl1 + (tap * C + lk) * C + li;
+                const float* xr = win + (h1 + (tap - h2) * g.dil + li) * P + lk;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const float b = wr[4 * qq * C];
+#pragma unroll
+                    for (int tt = 0; tt < 5; ++tt) {
+                        // (the fifth tile reads up to 80 - (64 + 2 h2) rows past the window: inside this wave's LDS region,
+                        // the rows of `mid`; its surplus outputs are never read by c2)
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[tt * 16 * P + 4 * qq], b, acc[tt], 0, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();      // every read of the x window is done before `mid` (behind it) is written
+#pragma unroll
+            for (int tt = 0; tt < 5; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int u = tt * 16 + 4 * lk + r;
+                    const int64_t t = t0 - h2 + u;
+                    float y = acc[tt][r] + bc1;
+                    y = y > 0.f ? y : y * g.slope;
+                    mid[u * P + li] = (t >= 0 && t < g.T) ? y : 0.f;       // c2 zero-pads its input
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- c2 (dilation 1) on frames t0 .. t0 + 63: mid row of output o at tap = o + tap ----
+        {
+            f32x4 acc[4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int tap = 0; tap < g.ktaps; ++tap) {
+                const float* wr = wl2 + (tap * C + lk) * C + li;
+                const float* xr = mid + (tap + li) * P + lk;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const float b = wr[4 * qq * C];
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt)
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[tt * 16 * P + 4 * qq], b, acc[tt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t t = t0 + tt * 16 + 4 * lk + r;
+                    if (t < g.T) {
+                        const int64_t o = t * C + li;
+                        const float y = acc[tt][r] + bc2 + g.x[o];
+                        if (g.out) g.out[o] = y;
+                        if (g.out_act) g.out_act[o] = y > 0.f ? y : y * g.slope;
+                    }
+                }
+        }
+        __builtin_amdgcn_wave_barrier();   // both windows are re-staged next
+        if (more) store_window();
+    }
+}
+
 // ---- the 32-channel stage with split-bf16 products -----------------------------------------------------------------------------
 // Same ownership as conv_small_kernel (a wavefront owns 64 frames, window + whole weight in the LDS), but window and weight
 // are converted to bf16 hi / lo halves ONCE while they are staged - row image [32 hi | 32 lo], 144 bytes apart so that the
@@ -381,6 +517,155 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
     const f32x2v rem = (f32x2v){a, b} - (f32x2v){__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(rem, bf16x2v));
 }
+// ---- one residual pair of the 16-channel stage with split-bf16 products (round 3) ---------------------------------------------
+// x -> x + c2(leaky_relu(c1_dilated(leaky_relu(x)))) reading only x and writing only the result: 56 MB per pair at 860 frames
+// where the two-launch form moves 224 MB (activated copies written by the producer for the consumer, the residual read apart).
+// A wavefront owns RT - 2 h2 output frames (RT = 16 NT rows; h2 = c2's halo): it stages the window of x it needs - activated and
+// converted to bf16 hi / lo halves once, row image [16 hi | 16 lo] 80 bytes apart - computes c1 on RT rows as
+// D[co][frame] = W[co][k] X[k][frame] with v_mfma_f32_16x16x32_bf16 (K = two taps x 16 input channels, three instructions per
+// fp32 product), writes the activated result (zero outside the signal, as c2 pads it) over the START of the same window - c1
+// is done with it - in the same row image, and runs c2 from there.  The accumulator layout (four consecutive output channels
+// of one frame per lane) makes both the LDS write and the global store whole 16-byte pieces.
+constexpr int P16 = 20;    // dwords per row image (80 bytes: sixteen consecutive rows start in sixteen different bank quads)
+constexpr int PW16 = 36;   // dwords per weight row image: one (tap pair, co) = [2 taps x 16 ci hi | the same lo], 144 bytes apart
+template <int NT>
+__global__ void __launch_bounds__(512) conv_pair16_bf16_kernel(ConvPairRawArgs g) {
+    constexpr int C = 16, RT = 16 * NT;
+    extern __shared__ uint32_t ldsu[];
+    const int h2 = (g.ktaps - 1) / 2, h1 = h2 * g.dil, npair = (g.ktaps + 1) / 2;
+    const int tw = RT - 2 * h2, rows = RT + 2 * h1;       // window row w <-> frame t0 - h2 - h1 + w
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    uint32_t* const wl1 = ldsu;
+    uint32_t* const wl2 = ldsu + npair * C * PW16;
+    uint32_t* const win = ldsu + 2 * npair * C * PW16 + wave * rows * P16;
+    for (int i = threadIdx.x; i < 2 * npair * C * PW16; i += blockDim.x) ldsu[i] = 0;     // (the tap after the last is a zero weight)
+    __syncthreads();
+    for (int i4 = threadIdx.x; i4 < g.ktaps * C * C / 4; i4 += blockDim.x) {             // four consecutive ci of one (co, tap)
+        const int e = i4 * 4, co = e / (g.ktaps * C), r = e % (g.ktaps * C), tap = r / C, ci = r % C;
+        const int at = ((tap >> 1) * C + co) * PW16 + ((tap & 1) * C + ci) / 2;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const f32x4 v = *(const f32x4*)((which ? g.w2 : g.w1) + e);
+            uint32_t ha, la, hb, lb;
+            split2(v[0], v[1], ha, la);
+            split2(v[2], v[3], hb, lb);
+            uint32_t* p = (which ? wl2 : wl1) + at;
+            p[0] = ha;
+            p[1] = hb;
+            p[16] = la;
+            p[17] = lb;
+        }
+    }
+    __syncthreads();
+    const int64_t nchunks = (g.T + tw - 1) / tw;
+    constexpr int NV = ((RT + 2 * 25) * C / 4 + 63) / 64;
+    const int nvec = rows * C / 4;
+    f32x4 pre[NV];
+    auto load_window = [&](int64_t t0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = (lane + 64 * i) * 4;
+            const int64_t t = t0 - h2 - h1 + e / C;
+            pre[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (lane + 64 * i < nvec && t >= 0 && t < g.T) pre[i] = *(const f32x4*)(g.x + t * C + e % C);
+        }
+    };
+    auto store_window = [&]() {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v4 = lane + 64 * i;
+            if (v4 < nvec) {
+                f32x4 v = pre[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * g.slope;
+                uint32_t ha, la, hb, lb;
+                split2(v[0], v[1], ha, la);
+                split2(v[2], v[3], hb, lb);
+                uint32_t* p = win + (v4 >> 2) * P16 + 2 * (v4 & 3);
+                *(ddsp_u32x2*)p = ddsp_u32x2{ha, hb};
+                *(ddsp_u32x2*)(p + 8) = ddsp_u32x2{la, lb};
+            }
+        }
+    };
+    const int li = lane & 15, lk = lane >> 4;
+    const f32x4 bc1 = g.b1 ? *(const f32x4*)(g.b1 + 4 * lk) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 bc2 = g.b2 ? *(const f32x4*)(g.b2 + 4 * lk) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t first = (int64_t)blockIdx.x * nwaves + wave, step = (int64_t)gridDim.x * nwaves;
+    if (first < nchunks) {
+        load_window(first * tw);
+        store_window();
+    }
+    // one convolution over NT tiles of 16 rows: `src` row of (output row u, tap) = u + tap * dd
+    auto conv = [&](const uint32_t* wl, const uint32_t* src, int dd, f32x4 (&acc)[NT]) {
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < npair; ++j) {
+            const uint32_t* wr = wl + (j * C + li) * PW16 + 4 * lk;
+            const nsf_bf16x8 wh = __builtin_bit_cast(nsf_bf16x8, *(const ddsp_u32x4*)wr);
+            const nsf_bf16x8 wlo = __builtin_bit_cast(nsf_bf16x8, *(const ddsp_u32x4*)(wr + 16));
+            int tap = 2 * j + (lk >> 1);
+            tap = tap < g.ktaps ? tap : g.ktaps - 1;          // the zero weight's data: any finite rows
+            const uint32_t* xr = src + (li + tap * dd) * P16 + 4 * (lk & 1);
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                const nsf_bf16x8 xh = __builtin_bit_cast(nsf_bf16x8, *(const ddsp_u32x4*)(xr + tt * 16 * P16));
+                const nsf_bf16x8 xl = __builtin_bit_cast(nsf_bf16x8, *(const ddsp_u32x4*)(xr + tt * 16 * P16 + 8));
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xh, acc[tt], 0, 0, 0);
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc[tt], 0, 0, 0);
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[tt], 0, 0, 0);
+            }
+        }
+    };
+    for (int64_t chunk = first; chunk < nchunks; chunk += step) {
+        const int64_t t0 = chunk * tw;
+        const bool more = chunk + step < nchunks;
+        f32x4 res[NT];                                         // the residual rows in the accumulator layout (cache hits: the
+#pragma unroll                                                 // window load fetched the same lines), asked for before the products
+        for (int tt = 0; tt < NT; ++tt) {
+            const int o = tt * 16 + li;
+            res[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (o < tw && t0 + o < g.T) res[tt] = *(const f32x4*)(g.x + (t0 + o) * C + 4 * lk);
+        }
+        if (more) load_window((chunk + step) * tw);
+        __builtin_amdgcn_wave_barrier();
+        f32x4 acc[NT];
+        conv(wl1, win, g.dil, acc);                            // c1 on frames t0 - h2 .. t0 - h2 + RT - 1
+        __builtin_amdgcn_wave_barrier();                       // every read of the window is done: its head becomes c2's input
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const int u = tt * 16 + li;
+            const int64_t t = t0 - h2 + u;
+            f32x4 y = acc[tt] + bc1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = (t >= 0 && t < g.T) ? (y[r] > 0.f ? y[r] : y[r] * g.slope) : 0.f;
+            uint32_t ha, la, hb, lb;
+            split2(y[0], y[1], ha, la);
+            split2(y[2], y[3], hb, lb);
+            uint32_t* p = win + u * P16 + 2 * lk;
+            *(ddsp_u32x2*)p = ddsp_u32x2{ha, hb};
+            *(ddsp_u32x2*)(p + 8) = ddsp_u32x2{la, lb};
+        }
+        __builtin_amdgcn_wave_barrier();
+        conv(wl2, win, 1, acc);                                // c2 on frames t0 .. t0 + RT - 1, of which tw are this window's
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const int o = tt * 16 + li;
+            if (o < tw && t0 + o < g.T) {
+                const int64_t at = (t0 + o) * C + 4 * lk;
+                f32x4 y = acc[tt] + bc2 + res[tt];
+                if (g.out) *(f32x4*)(g.out + at) = y;
+                if (g.out_act) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] = y[r] > 0.f ? y[r] : y[r] * g.slope;
+                    *(f32x4*)(g.out_act + at) = y;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();   // the window is re-staged next
+        if (more) store_window();
+    }
+}
+
 template <int NT>   // frame tiles of 32 per window: 2, or 1 when the halo would otherwise leave fewer than 8 windows in the LDS
 __global__ void __launch_bounds__(512) conv_small32_bf16_kernel(ConvSmallArgs g) {   // 4 .. 8 waves: as many windows as fit the LDS beside the weight
     constexpr int C = 32, TWK = 32 * NT;
@@ -576,6 +861,56 @@ struct EpiAddBias {   // y = acc + bias[n] (+ res): C = y and / or Cact = leaky_
 };
 
 }  // namespace
+
+// ---- one ResBlock1 pair x -> x + c2(leaky_relu(c1_dilated(leaky_relu(x)))) in one launch ---------------------------------------
+static size_t pair16_bf16_lds(int ktaps, int dil, int nt, int nw) {
+    const int npair = (ktaps + 1) / 2, rows = 16 * nt + (ktaps - 1) * dil;
+    return ((size_t)2 * npair * 16 * PW16 + (size_t)nw * rows * P16) * sizeof(uint32_t);
+}
+// 1 when ddsp_conv1d_pair takes this geometry in the context's arithmetic
+extern "C" int ddsp_conv1d_pair_supported(ddsp_ctx* ctx, int C, int ktaps, int dil) {
+    if (!ctx || ktaps < 1 || ktaps % 2 == 0 || ktaps > 11 || dil < 1 || dil > 5) return 0;
+    return C == 16 ? 1 : 0;
+}
+extern "C" int ddsp_conv1d_pair(ddsp_ctx* ctx, void* stream, const float* x, const float* w1, const float* b1, const float* w2,
+                                const float* b2, int64_t T, int C, int ktaps, int dil, float slope, float* out, float* out_act) {
+    DDSP_REQUIRE(ctx, ctx && x && w1 && w2 && (out || out_act), "ddsp_conv1d_pair: null argument");
+    DDSP_REQUIRE(ctx, T >= 1 && T < (1 << 30), "ddsp_conv1d_pair: bad length");
+    DDSP_REQUIRE(ctx, ddsp_conv1d_pair_supported(ctx, C, ktaps, dil) == 1,
+                 "ddsp_conv1d_pair: 16 channels, odd tap counts up to 11, dilation up to 5 (ask ddsp_conv1d_pair_supported)");
+    DDSP_REQUIRE(ctx, (((uintptr_t)x | (uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)out | (uintptr_t)out_act) % 16) == 0 &&
+                          x != out && x != out_act,
+                 "ddsp_conv1d_pair: 16-byte aligned tensors, not in place");
+    hipStream_t st = (hipStream_t)stream;
+    DDSP_ENTER_DEVICE(ctx);
+    ConvPairRawArgs a{x, w1, b1, w2, b2, out, out_act, T, ktaps, dil, slope};
+    ddsp_prof_begin(ctx, st, PF_OTHER);
+    if (ctx->math == DDSP_MATH_FP32) {
+        const int halo = (ktaps - 1) / 2 * (dil + 1), rows = CS_TW + 2 * halo;
+        const size_t lds = ((size_t)2 * ktaps * C * C + 4 * (size_t)(rows + CP_MID) * (C + 1)) * sizeof(float);
+        DDSP_ONCE_PER_DEVICE(ctx, DDSP_HIP(ctx, hipFuncSetAttribute((const void*)conv_pair16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+        const int64_t nchunks = (T + CS_TW - 1) / CS_TW;
+        int64_t blocks = (nchunks + 3) / 4;
+        const int64_t cap = 256 * (lds > 80 * 1024 ? 1 : lds > 53 * 1024 ? 2 : 3);
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL(conv_pair16_kernel, dim3((unsigned)blocks), dim3(256), lds, st, a);
+    } else {
+        constexpr int NT = 6;
+        int nw = 8;
+        while (nw > 1 && pair16_bf16_lds(ktaps, dil, NT, nw) > 160 * 1024) --nw;
+        const size_t lds = pair16_bf16_lds(ktaps, dil, NT, nw);
+        DDSP_ONCE_PER_DEVICE(ctx, DDSP_HIP(ctx, hipFuncSetAttribute((const void*)conv_pair16_bf16_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+        const int tw = 16 * NT - (ktaps - 1);
+        const int64_t nchunks = (T + tw - 1) / tw;
+        int64_t blocks = (nchunks + nw - 1) / nw;
+        const int64_t cap = 256 * (lds > 80 * 1024 ? 1 : 2);
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL(conv_pair16_bf16_kernel<NT>, dim3((unsigned)blocks), dim3(64 * nw), lds, st, a);
+    }
+    ddsp_prof_end(ctx, st, 4.0 * T * C * C * ktaps, 8.0 * T * C);
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}
 
 extern "C" int ddsp_conv1d(ddsp_ctx* ctx, void* stream, const float* x, const float* w_packed, const float* bias, int64_t T,
                            int Cin, int Cout, int ktaps, int dil, float in_slope, const float* residual, float* out,

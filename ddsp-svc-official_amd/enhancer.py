@@ -22,6 +22,8 @@ import torch.nn.functional as F
 import hipddsp
 from resample import Resample
 
+PAIR_FUSION = os.environ.get("DDSP_CONV_PAIR", "1") != "0"   # measurement aid: 0 = two launches per residual pair
+
 LRELU_SLOPE = 0.1
 
 
@@ -274,9 +276,15 @@ class Generator(torch.nn.Module):
             T_out = T * u
             x_source = c.nsf_noise_conv(src, nw, nb, nk, ns, npad, T_out)                          # (T_out, cout)
             s_out = can_split(cin, cout)
-            up, up_act = c.conv1d(cur_act, w_up, b_up, 3, 1, 1.0, residual=x_source.reshape(T, u * cout), act_slope=LRELU_SLOPE,
-                                  w_split=w_up_s if (act_s or s_out) else None, x_split=act_s, act_split=s_out)
-            cur, cur_act = up.reshape(T_out, cout), up_act.reshape(T_out, cout)
+            # a narrow stage whose residual pairs run fused (x in, x out, activations on load: csrc/nsf.hip, conv_pair*) needs no
+            # activated copies at all
+            fused = PAIR_FUSION and all(c.conv1d_pair_supported(cout, k, d) for convs in P["res"][i] for (_, _, _, d, _, _, _, k) in convs)
+            up, up_act = c.conv1d(cur_act, w_up, b_up, 3, 1, 1.0, residual=x_source.reshape(T, u * cout),
+                                  act_slope=None if fused else LRELU_SLOPE,
+                                  w_split=w_up_s if (act_s or s_out) else None, x_split=act_s, act_split=s_out), None
+            if not fused:
+                up, up_act = up
+            cur, cur_act = up.reshape(T_out, cout), None if fused else up_act.reshape(T_out, cout)
             T = T_out
             outs = []
             s = s_out                                 # inside a stage every convolution is cout -> cout
@@ -284,6 +292,9 @@ class Generator(torch.nn.Module):
             for convs in P["res"][i]:
                 xr, xr_act = cur, cur_act
                 for t, (w1, w1s, b1, d, w2, w2s, b2, k) in enumerate(convs):
+                    if fused:
+                        xr, _ = c.conv1d_pair(xr, w1, b1, w2, b2, k, d, LRELU_SLOPE)
+                        continue
                     _, xt_act = c.conv1d(xr_act, w1, b1, k, d, 1.0, want_out=False, act_slope=LRELU_SLOPE,
                                          w_split=w1s if ws_ok else None, x_split=s, act_split=s)
                     if t + 1 < len(convs):

@@ -89,6 +89,8 @@ SIGNATURES = {
     "ddsp_phase_vocoder": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
     "ddsp_volume_extract": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp]),
     "ddsp_align_units": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp]),
+    "ddsp_conv1d_pair_supported": (_int, [_vp, _int, _int, _int]),
+    "ddsp_conv1d_pair": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _f32, _vp, _vp]),
     "ddsp_retime_f0": (_int, [_vp, _vp, _vp, _i64, _f64, _f64, _f32, _f64, _i64, _vp]),
     "ddsp_resample_length": (_i64, [_i64, _int, _int]),
     "ddsp_resample": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _int, _vp]),
@@ -464,6 +466,19 @@ class Context:
                   _ptr(residual), _ptr(out), _ptr(act), float(act_slope if act_slope is not None else 1.0), _ptr(w_split),
                   (CONV_X_SPLIT if x_split else 0) | (CONV_ACT_SPLIT if act_split else 0))
         return out if act_slope is None else (out, act)
+
+    def conv1d_pair_supported(self, C, ktaps, dil):
+        return bool(self.lib.ddsp_conv1d_pair_supported(self.handle, int(C), int(ktaps), int(dil)))
+
+    def conv1d_pair(self, x, w1, b1, w2, b2, ktaps, dil, slope, want_out=True, want_act=False):
+        """One ResBlock1 pair of a narrow stage: x (T,C) raw -> (x + c2(leaky_relu(c1_dil(leaky_relu(x)))), its activated copy);
+        either may be skipped (None)."""
+        T, C = x.shape
+        out = torch.empty(T, C, device=x.device, dtype=torch.float32) if want_out else None
+        act = torch.empty(T, C, device=x.device, dtype=torch.float32) if want_act else None
+        self.call("ddsp_conv1d_pair", _ptr(x), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), T, C, int(ktaps), int(dil), float(slope),
+                  _ptr(out), _ptr(act))
+        return out, act
 
     def nsf_source(self, f0, rand_ini, lin_w, lin_b, upp, sr, sine_amp=0.1):
         L = f0.numel()

@@ -305,6 +305,15 @@ int ddsp_resample(ddsp_ctx* ctx, void* stream, const float* x, int64_t B, int64_
 int ddsp_conv1d(ddsp_ctx* ctx, void* stream, const float* x, const float* w_packed, const float* bias, int64_t T, int Cin,
                 int Cout, int ktaps, int dil, float in_slope, const float* residual, float* out, float* out_act,
                 float act_slope, const float* w_split, int flags);
+/* One residual pair of `ResBlock1` (nsf_hifigan/models.py:41-90: xt = c1(leaky_relu(x)); xt = c2(leaky_relu(xt)); x = xt + x) of a
+ * narrow stage in one launch: x (T,C) raw, c1 with `dil`, c2 with dilation 1, both `ktaps` taps, weights packed as for
+ * ddsp_conv1d; out = the new x, out_act = leaky_relu(out, slope) (either may be null).  Only x is read and the results
+ * written: the activations happen on load and c1's output stays in the LDS.  Products follow the context's arithmetic.
+ * ddsp_conv1d_pair_supported: 1 when (C, ktaps, dil) is a geometry the fused kernel takes (else use two ddsp_conv1d calls). */
+int ddsp_conv1d_pair_supported(ddsp_ctx* ctx, int C, int ktaps, int dil);
+int ddsp_conv1d_pair(ddsp_ctx* ctx, void* stream, const float* x, const float* w1, const float* b1, const float* w2,
+                     const float* b2, int64_t T, int C, int ktaps, int dil, float slope, float* out, float* out_act);
+
 int ddsp_nsf_source(ddsp_ctx* ctx, void* stream, const float* f0, const float* rand_ini, const float* lin_w,
                     const float* lin_b, int64_t L, int upp, int sr, float sine_amp, float* out);
 int ddsp_nsf_noise_conv(ddsp_ctx* ctx, void* stream, const float* src, int64_t T_src, const float* w, const float* b, int C,
