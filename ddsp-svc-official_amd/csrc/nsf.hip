@@ -862,22 +862,217 @@ struct EpiAddBias {   // y = acc + bias[n] (+ res): C = y and / or Cact = leaky_
 
 }  // namespace
 
+// ---- the same for the 32-channel stage: v_mfma_f32_32x32x16_bf16, two k-steps per tap, row images as in conv_small32_bf16_kernel ----
+// Both weights (hi / lo: 4 bytes a weight, 2 x 50 KB at 11 taps) stay in the LDS, so the number of windows (wavefronts) of a
+// workgroup follows from what is left: 8 at 3 taps, 7 at 7, 3 - 5 at 11 (NT = 1: 32-row windows there when that wins).
+template <int NT>
+__global__ void __launch_bounds__(512) conv_pair32_bf16_kernel(ConvPairRawArgs g) {
+    constexpr int C = 32, RT = 32 * NT;
+    extern __shared__ uint32_t ldsu[];
+    const int h2 = (g.ktaps - 1) / 2, h1 = h2 * g.dil;
+    const int tw = RT - 2 * h2, rows = RT + 2 * h1;       // window row w <-> frame t0 - h2 - h1 + w
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    uint32_t* const wl1 = ldsu;
+    uint32_t* const wl2 = ldsu + g.ktaps * C * CB_PITCH;
+    float* const bias = (float*)(ldsu + 2 * g.ktaps * C * CB_PITCH);                      // b1 | b2
+    uint32_t* const win = ldsu + 2 * g.ktaps * C * CB_PITCH + 2 * C + wave * rows * CB_PITCH;
+    for (int i4 = threadIdx.x; i4 < g.ktaps * C * C / 4; i4 += blockDim.x) {             // four consecutive ci of one (co, tap)
+        const int e = i4 * 4, co = e / (g.ktaps * C), r = e % (g.ktaps * C), tap = r / C, ci = r % C;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const f32x4 v = *(const f32x4*)((which ? g.w2 : g.w1) + e);
+            uint32_t ha, la, hb, lb;
+            split2(v[0], v[1], ha, la);
+            split2(v[2], v[3], hb, lb);
+            uint32_t* p = (which ? wl2 : wl1) + (tap * C + co) * CB_PITCH + ci / 2;
+            p[0] = ha;
+            p[1] = hb;
+            p[16] = la;
+            p[17] = lb;
+        }
+    }
+    if (threadIdx.x < 2 * C) {
+        const float* b = threadIdx.x < C ? g.b1 : g.b2;
+        bias[threadIdx.x] = b ? b[threadIdx.x % C] : 0.f;
+    }
+    __syncthreads();
+    const int64_t nchunks = (g.T + tw - 1) / tw;
+    constexpr int NV = ((RT + 2 * 25) * C / 4 + 63) / 64;
+    const int nvec = rows * C / 4;
+    f32x4 pre[NV];
+    auto load_window = [&](int64_t t0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = (lane + 64 * i) * 4;
+            const int64_t t = t0 - h2 - h1 + e / C;
+            pre[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (lane + 64 * i < nvec && t >= 0 && t < g.T) pre[i] = *(const f32x4*)(g.x + t * C + e % C);
+        }
+    };
+    auto store_window = [&]() {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v4 = lane + 64 * i;
+            if (v4 < nvec) {
+                f32x4 v = pre[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * g.slope;
+                uint32_t ha, la, hb, lb;
+                split2(v[0], v[1], ha, la);
+                split2(v[2], v[3], hb, lb);
+                uint32_t* p = win + (v4 >> 3) * CB_PITCH + 2 * (v4 & 7);
+                *(ddsp_u32x2*)p = ddsp_u32x2{ha, hb};
+                *(ddsp_u32x2*)(p + 16) = ddsp_u32x2{la, lb};
+            }
+        }
+    };
+    const int li = lane & 31, lh = lane >> 5;
+    const int64_t first = (int64_t)blockIdx.x * nwaves + wave, step = (int64_t)gridDim.x * nwaves;
+    if (first < nchunks) {
+        load_window(first * tw);
+        store_window();
+    }
+    // D[co = (r & 3) + 8 (r >> 2) + 4 lh][frame = li] = bias[co] + sum over (tap, ci) of W[co][tap, ci] * src[frame + tap * dd][ci]
+    auto conv = [&](const uint32_t* wl, const float* bz, const uint32_t* src, int dd, f32x16 (&acc)[NT]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *(const f32x4*)(bz + 8 * q + 4 * lh);
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[tt][4 * q + r] = b[r];
+        }
+        for (int tap = 0; tap < g.ktaps; ++tap) {
+            const uint32_t* wr = wl + (tap * C + li) * CB_PITCH + 4 * lh;
+            const uint32_t* xr = src + (li + tap * dd) * CB_PITCH + 4 * lh;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const nsf_bf16x8 wh = __builtin_bit_cast(nsf_bf16x8, *(const ddsp_u32x4*)(wr + 8 * s));
+                const nsf_bf16x8 wlo = __builtin_bit_cast(nsf_bf16x8, *(const ddsp_u32x4*)(wr + 8 * s + 16));
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    const nsf_bf16x8 xh = __builtin_bit_cast(nsf_bf16x8, *(const ddsp_u32x4*)(xr + tt * 32 * CB_PITCH + 8 * s));
+                    const nsf_bf16x8 xl = __builtin_bit_cast(nsf_bf16x8, *(const ddsp_u32x4*)(xr + tt * 32 * CB_PITCH + 8 * s + 16));
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xh, acc[tt], 0, 0, 0);
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[tt], 0, 0, 0);
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[tt], 0, 0, 0);
+                }
+            }
+        }
+    };
+    for (int64_t chunk = first; chunk < nchunks; chunk += step) {
+        const int64_t t0 = chunk * tw;
+        const bool more = chunk + step < nchunks;
+        f32x4 res[NT][4];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const int o = tt * 32 + li;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                res[tt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (o < tw && t0 + o < g.T) res[tt][q] = *(const f32x4*)(g.x + (t0 + o) * C + 8 * q + 4 * lh);
+            }
+        }
+        if (more) load_window((chunk + step) * tw);
+        __builtin_amdgcn_wave_barrier();
+        f32x16 acc[NT];
+        conv(wl1, bias, win, g.dil, acc);
+        __builtin_amdgcn_wave_barrier();                       // every read of the window is done: its head becomes c2's input
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const int u = tt * 32 + li;
+            const int64_t t = t0 - h2 + u;
+            const bool in = t >= 0 && t < g.T;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float y[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[tt][4 * q + r];
+                    y[r] = in ? (v > 0.f ? v : v * g.slope) : 0.f;
+                }
+                uint32_t ha, la, hb, lb;
+                split2(y[0], y[1], ha, la);
+                split2(y[2], y[3], hb, lb);
+                uint32_t* p = win + u * CB_PITCH + 4 * q + 2 * lh;
+                *(ddsp_u32x2*)p = ddsp_u32x2{ha, hb};
+                *(ddsp_u32x2*)(p + 16) = ddsp_u32x2{la, lb};
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        conv(wl2, bias + C, win, 1, acc);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const int o = tt * 32 + li;
+            if (o < tw && t0 + o < g.T) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t at = (t0 + o) * C + 8 * q + 4 * lh;
+                    f32x4 y = res[tt][q];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] += acc[tt][4 * q + r];
+                    if (g.out) *(f32x4*)(g.out + at) = y;
+                    if (g.out_act) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[r] = y[r] > 0.f ? y[r] : y[r] * g.slope;
+                        *(f32x4*)(g.out_act + at) = y;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();   // the window is re-staged next
+        if (more) store_window();
+    }
+}
+
 // ---- one ResBlock1 pair x -> x + c2(leaky_relu(c1_dilated(leaky_relu(x)))) in one launch ---------------------------------------
 static size_t pair16_bf16_lds(int ktaps, int dil, int nt, int nw) {
     const int npair = (ktaps + 1) / 2, rows = 16 * nt + (ktaps - 1) * dil;
     return ((size_t)2 * npair * 16 * PW16 + (size_t)nw * rows * P16) * sizeof(uint32_t);
 }
 // 1 when ddsp_conv1d_pair takes this geometry in the context's arithmetic
+// the 32-channel kernel's window height (tiles of 32 rows) and wavefront count for a geometry: both weights stay in the LDS
+static void pair32_shape(int ktaps, int dil, int& nt, int& nw, size_t& lds) {
+    const size_t fixed = ((size_t)2 * ktaps * 32 * CB_PITCH + 64) * sizeof(uint32_t);
+    double best = 1e30;
+    nt = 0;
+    nw = 0;
+    lds = 0;
+    for (int cand = 2; cand >= 1; --cand) {
+        const int rt = 32 * cand, tw = rt - (ktaps - 1), rows = rt + (ktaps - 1) * dil;
+        if (tw < 8) continue;
+        const size_t per = (size_t)rows * CB_PITCH * sizeof(uint32_t);
+        if (fixed + per > 160 * 1024) continue;
+        int n = (int)((160 * 1024 - fixed) / per);
+        n = n > 8 ? 8 : n;
+        // matrix time per output frame with n wavefronts on 4 SIMDs, computed rows over delivered frames
+        const double cost = ((double)rt / tw) / (n < 4 ? n : 4);
+        if (cost < best * 0.97) {
+            best = cost;
+            nt = cand;
+            nw = n;
+            lds = fixed + n * per;
+        }
+    }
+}
+// 1 when ddsp_conv1d_pair takes this geometry in the context's arithmetic
 extern "C" int ddsp_conv1d_pair_supported(ddsp_ctx* ctx, int C, int ktaps, int dil) {
     if (!ctx || ktaps < 1 || ktaps % 2 == 0 || ktaps > 11 || dil < 1 || dil > 5) return 0;
-    return C == 16 ? 1 : 0;
+    if (C == 16) return 1;
+    if (C == 32 && ctx->math != DDSP_MATH_FP32) {
+        int nt, nw;
+        size_t lds;
+        pair32_shape(ktaps, dil, nt, nw, lds);
+        return nw >= 2 ? 1 : 0;
+    }
+    return 0;
 }
 extern "C" int ddsp_conv1d_pair(ddsp_ctx* ctx, void* stream, const float* x, const float* w1, const float* b1, const float* w2,
                                 const float* b2, int64_t T, int C, int ktaps, int dil, float slope, float* out, float* out_act) {
     DDSP_REQUIRE(ctx, ctx && x && w1 && w2 && (out || out_act), "ddsp_conv1d_pair: null argument");
     DDSP_REQUIRE(ctx, T >= 1 && T < (1 << 30), "ddsp_conv1d_pair: bad length");
     DDSP_REQUIRE(ctx, ddsp_conv1d_pair_supported(ctx, C, ktaps, dil) == 1,
-                 "ddsp_conv1d_pair: 16 channels, odd tap counts up to 11, dilation up to 5 (ask ddsp_conv1d_pair_supported)");
+                 "ddsp_conv1d_pair: 16 channels (32 with split-bf16 products), odd tap counts up to 11, dilation up to 5 (ask ddsp_conv1d_pair_supported)");
     DDSP_REQUIRE(ctx, (((uintptr_t)x | (uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)out | (uintptr_t)out_act) % 16) == 0 &&
                           x != out && x != out_act,
                  "ddsp_conv1d_pair: 16-byte aligned tensors, not in place");
@@ -885,7 +1080,21 @@ extern "C" int ddsp_conv1d_pair(ddsp_ctx* ctx, void* stream, const float* x, con
     DDSP_ENTER_DEVICE(ctx);
     ConvPairRawArgs a{x, w1, b1, w2, b2, out, out_act, T, ktaps, dil, slope};
     ddsp_prof_begin(ctx, st, PF_OTHER);
-    if (ctx->math == DDSP_MATH_FP32) {
+    if (C == 32) {
+        int nt, nw;
+        size_t lds;
+        pair32_shape(ktaps, dil, nt, nw, lds);
+        DDSP_ONCE_PER_DEVICE(ctx, DDSP_HIP(ctx, hipFuncSetAttribute((const void*)conv_pair32_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                             DDSP_HIP(ctx, hipFuncSetAttribute((const void*)conv_pair32_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+        const int tw = 32 * nt - (ktaps - 1);
+        const int64_t nchunks = (T + tw - 1) / tw;
+        int64_t blocks = (nchunks + nw - 1) / nw;
+        if (blocks > 256) blocks = 256;
+        if (nt == 2)
+            hipLaunchKernelGGL(conv_pair32_bf16_kernel<2>, dim3((unsigned)blocks), dim3(64 * nw), lds, st, a);
+        else
+            hipLaunchKernelGGL(conv_pair32_bf16_kernel<1>, dim3((unsigned)blocks), dim3(64 * nw), lds, st, a);
+    } else if (ctx->math == DDSP_MATH_FP32) {
         const int halo = (ktaps - 1) / 2 * (dil + 1), rows = CS_TW + 2 * halo;
         const size_t lds = ((size_t)2 * ktaps * C * C + 4 * (size_t)(rows + CP_MID) * (C + 1)) * sizeof(float);
         DDSP_ONCE_PER_DEVICE(ctx, DDSP_HIP(ctx, hipFuncSetAttribute((const void*)conv_pair16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
@@ -903,8 +1112,7 @@ extern "C" int ddsp_conv1d_pair(ddsp_ctx* ctx, void* stream, const float* x, con
         const int tw = 16 * NT - (ktaps - 1);
         const int64_t nchunks = (T + tw - 1) / tw;
         int64_t blocks = (nchunks + nw - 1) / nw;
-        const int64_t cap = 256 * (lds > 80 * 1024 ? 1 : 2);
-        if (blocks > cap) blocks = cap;
+        if (blocks > 256) blocks = 256;       // (210 VGPRs: the 8 wavefronts of one workgroup are a CU's share)
         hipLaunchKernelGGL(conv_pair16_bf16_kernel<NT>, dim3((unsigned)blocks), dim3(64 * nw), lds, st, a);
     }
     ddsp_prof_end(ctx, st, 4.0 * T * C * C * ktaps, 8.0 * T * C);

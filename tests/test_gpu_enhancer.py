@@ -112,39 +112,44 @@ def test_conv1d_building_block(ctx, dev):
         ctx.conv1d(x.to(dev), wp.to(dev), b.to(dev), 2, 1, 1.0)          # even tap counts are not "same"-paddable
 
 
-@pytest.mark.parametrize("math", ["split_bf16", "fp32"])
-def test_conv1d_residual_pair(ctx, dev, math):
-    """`ddsp_conv1d_pair` (one ResBlock1 pair of the 16-channel stage in one launch: x in, x out, activations on load, c1's
-    output kept in the LDS) against torch's conv1d in fp64 and against the two-launch path: every kernel size / dilation the
-    shipped generator has, signal lengths around the window sizes (c2's zero padding of c1's OUTPUT at both ends of the signal
-    is the case a fused kernel gets wrong), in both arithmetics (fp32 MFMA / three bf16 products per fp32 product)."""
+@pytest.mark.parametrize("math,C", [("split_bf16", 16), ("fp32", 16), ("split_bf16", 32)])
+def test_conv1d_residual_pair(ctx, dev, math, C):
+    """`ddsp_conv1d_pair` (one ResBlock1 pair of a narrow stage in one launch: x in, x out, activations on load, c1's output
+    kept in the LDS) against torch's conv1d in fp64 and against the two-launch path: every kernel size / dilation the shipped
+    generator has, signal lengths around the window sizes (c2's zero padding of c1's OUTPUT at both ends of the signal is the
+    case a fused kernel gets wrong), 16 channels in both arithmetics (fp32 MFMA / three bf16 products per fp32 product), 32
+    channels in split arithmetic (with fp32 products the 32-channel stage stays on two GEMM launches)."""
     import hipddsp
     F = torch.nn.functional
     g = torch.Generator().manual_seed(11)
     ctx.set_math(hipddsp.MATH_SPLIT_BF16 if math == "split_bf16" else hipddsp.MATH_FP32)
     try:
         for (T, k, d) in [(1, 3, 1), (5, 11, 5), (63, 3, 3), (64, 7, 5), (65, 11, 1), (86, 11, 3), (87, 11, 3), (130, 11, 3),
-                          (4099, 11, 5), (20000, 7, 3), (777, 3, 5), (90, 3, 1), (91, 1, 1)]:
-            assert ctx.conv1d_pair_supported(16, k, d)
-            x = torch.randn(T, 16, generator=g)
-            w1, w2 = (torch.randn(16, 16, k, generator=g) / np.sqrt(16 * k) for _ in range(2))
-            b1, b2 = torch.randn(16, generator=g), torch.randn(16, generator=g)
+                          (4099, 11, 5), (20000, 7, 3), (777, 3, 5), (90, 3, 1), (91, 1, 1), (22, 11, 5), (23, 11, 5), (54, 11, 1),
+                          (55, 11, 1), (3000, 7, 1), (3001, 3, 3)]:
+            assert ctx.conv1d_pair_supported(C, k, d)
+            x = torch.randn(T, C, generator=g)
+            w1, w2 = (torch.randn(C, C, k, generator=g) / np.sqrt(C * k) for _ in range(2))
+            b1, b2 = torch.randn(C, generator=g), torch.randn(C, generator=g)
             xa = F.leaky_relu(x.double(), 0.1).t()[None]
             xt = F.conv1d(xa, w1.double(), b1.double(), dilation=d, padding=(k * d - d) // 2)
             want = (F.conv1d(F.leaky_relu(xt, 0.1), w2.double(), b2.double(), padding=(k - 1) // 2)[0].t() + x.double())
-            pk = lambda w: w.permute(0, 2, 1).reshape(16, -1).contiguous().to(dev)
+            pk = lambda w: w.permute(0, 2, 1).reshape(C, -1).contiguous().to(dev)
             xd = x.to(dev)
             out, act = ctx.conv1d_pair(xd, pk(w1), b1.to(dev), pk(w2), b2.to(dev), k, d, 0.1, want_act=True)
             assert float((out.cpu().double() - want).abs().max()) < (4e-5 if math == "split_bf16" else 2e-5), (T, k, d)
             assert torch.equal(act, F.leaky_relu(out, 0.1))
             _, mid = ctx.conv1d(xd, pk(w1), b1.to(dev), k, d, 0.1, want_out=False, act_slope=0.1)
             two, _ = ctx.conv1d(mid, pk(w2), b2.to(dev), k, 1, 1.0, residual=xd, act_slope=0.1)
-            assert float((out - two).abs().max()) < (4e-5 if math == "split_bf16" else 2e-6), (T, k, d)
+            assert float((out - two).abs().max()) < (6e-5 if math == "split_bf16" else 2e-6), (T, k, d)
             only_act = ctx.conv1d_pair(xd, pk(w1), b1.to(dev), pk(w2), b2.to(dev), k, d, 0.1, want_out=False, want_act=True)
             assert only_act[0] is None and torch.equal(only_act[1], act)
-        assert not ctx.conv1d_pair_supported(16, 4, 1) and not ctx.conv1d_pair_supported(16, 13, 1)
+        assert not ctx.conv1d_pair_supported(C, 4, 1) and not ctx.conv1d_pair_supported(C, 13, 1) and not ctx.conv1d_pair_supported(64, 3, 1)
         with pytest.raises(ValueError):
             ctx.conv1d_pair(xd, pk(w1), b1.to(dev), pk(w2), b2.to(dev), 4, 1, 0.1)
+        if C == 32:
+            ctx.set_math(hipddsp.MATH_FP32)
+            assert not ctx.conv1d_pair_supported(32, 3, 1)
     finally:
         ctx.set_math(hipddsp.MATH_SPLIT_BF16)
 
