@@ -75,11 +75,10 @@ struct ScanOut {
     float* phase_frames;
 };
 
-// VEC8: hop == 512 and 16-byte aligned outputs - a lane owns exactly 8 consecutive samples = 32 contiguous bytes per
-// output array, which leave as two 16-byte stores.  (As dword stores each instruction scattered 64 x 4 bytes at a
-// 32-byte stride over 16 cache lines and the kernel was store-issue-bound at 0.65 TB/s.)  The arithmetic per sample
-// is the same in both instantiations.
-template <bool PRECISE, bool VEC8 = false>
+// Any hop up to 1024 (a lane owns ceil(hop / 64) consecutive samples, dword stores).  hop == 512 with 16-byte aligned outputs
+// - every shipped configuration - runs frame_scan512_kernel below: the same arithmetic per sample, 32 contiguous bytes per lane
+// and output array leaving as two 16-byte stores.
+template <bool PRECISE>
 __global__ void __launch_bounds__(256) frame_scan_kernel(const float* __restrict__ f0_frames,
                                                          const double* __restrict__ frame_sum,
                                                          const float* __restrict__ initial_phase,
@@ -100,8 +99,8 @@ __global__ void __launch_bounds__(256) frame_scan_kernel(const float* __restrict
     for (int i = lane; i < m; i += 64) before += frame_sum[b * Fr + i];
     before = wave_sum_d(before);
 
-    constexpr int NL = VEC8 ? 8 : 16;
-    const int per_lane = VEC8 ? 8 : (hop + 63) / 64;  // host guarantees per_lane <= 16
+    constexpr int NL = 16;
+    const int per_lane = (hop + 63) / 64;  // host guarantees per_lane <= 16
     float fval[NL];
     double local[NL];
     double run = 0.0;
@@ -136,7 +135,6 @@ __global__ void __launch_bounds__(256) frame_scan_kernel(const float* __restrict
     const float pi_f = 3.14159274101257324f;
     const int64_t t0 = fidx * (int64_t)hop;
 
-    float r_v[VEC8 ? 8 : 1], ph_v[VEC8 ? 8 : 1], c_v[VEC8 ? 8 : 1];
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         if (i < per_lane) {
@@ -184,30 +182,146 @@ __global__ void __launch_bounds__(256) frame_scan_kernel(const float* __restrict
                     c = (x == 0.0f) ? 1.0f : sn * __builtin_amdgcn_rcpf(px);
                     if (comb_mode == DDSP_COMB_SINC_GATED && fval[i] <= 0.0f) c = 0.0f;
                 }
-                if constexpr (VEC8) {
-                    r_v[i] = r;
-                    ph_v[i] = ph;
-                    c_v[i] = c;
-                } else {
-                    if (out.rot) out.rot[t] = r;
-                    if (out.phase) out.phase[t] = ph;
-                    if (out.f0_up) out.f0_up[t] = fval[i];
-                    if (out.comb) out.comb[t] = c;
-                }
+                if (out.rot) out.rot[t] = r;
+                if (out.phase) out.phase[t] = ph;
+                if (out.f0_up) out.f0_up[t] = fval[i];
+                if (out.comb) out.comb[t] = c;
             }
         }
     }
-    if constexpr (VEC8) {
-        auto put = [&](float* dst, const float (&v)[8]) {
-            if (!dst) return;
-            float* q = dst + t0 + lane * 8;
-            *(f32x4*)q = f32x4{v[0], v[1], v[2], v[3]};
-            *(f32x4*)(q + 4) = f32x4{v[4], v[5], v[6], v[7]};
-        };
-        put(out.rot, r_v);
-        put(out.phase, ph_v);
-        put(out.f0_up, fval);
-        put(out.comb, c_v);
+}
+
+// ---- hop == 512 (every shipped configuration): the two passes without the generic path's per-sample bounds tests --------------
+// scale = Fr / (Fr * 512) is exactly 2^-9 in fp32, so src = scale * t is exact and w1 = (t mod 512) / 512 = lane / 64 + i / 512
+// needs no conversion per sample.  The in-frame prefix is a DPP scan (row shifts and row broadcasts of the two halves of the
+// fp64 value) instead of six LDS-crossbar shuffles; the preceding frames' sums are reduced the same way.  The sums themselves
+// are unchanged: the same fp32 frame values, the same fp64 increments, added in fp64.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_fetch_d(double v) {
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __builtin_bit_cast(double, ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+__device__ __forceinline__ double wave_incl_scan_dpp(double v) {
+    v += dpp_fetch_d<0x111, 0xf>(v);   // row_shr:1
+    v += dpp_fetch_d<0x112, 0xf>(v);   // row_shr:2
+    v += dpp_fetch_d<0x114, 0xf>(v);   // row_shr:4
+    v += dpp_fetch_d<0x118, 0xf>(v);   // row_shr:8
+    v += dpp_fetch_d<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v += dpp_fetch_d<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ double wave_total_of_scan(double incl) {
+    const uint64_t u = __builtin_bit_cast(uint64_t, incl);
+    const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)u, 63), hi = __builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), 63);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
+template <bool PRECISE>
+__global__ void __launch_bounds__(256) frame_sum512_kernel(const float* __restrict__ f0_frames, int64_t n_frames_total, int Fr,
+                                                           int sr, double* __restrict__ frame_sum) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t fidx = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);   // (the host holds B * Fr below 2^31)
+    if (fidx >= n_frames_total) return;
+    const int m = (int)(fidx % (uint32_t)Fr);
+    const float x0 = f0_frames[fidx];
+    const float x1 = (m + 1 < Fr) ? f0_frames[fidx + 1] : x0;
+    const float srf = (float)sr;
+    const double srd = PRECISE ? 1.0 / (double)sr : (double)sr;
+    const float wb = (float)lane * 0.015625f;
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += increment<PRECISE>(lerp_frame(x0, x1, wb + (float)i * 0.001953125f), srf, srd);
+    acc = wave_total_of_scan(wave_incl_scan_dpp(acc));
+    if (lane == 0) frame_sum[fidx] = acc;
+}
+
+template <bool PRECISE>
+__global__ void __launch_bounds__(256) frame_scan512_kernel(const float* __restrict__ f0_frames, const double* __restrict__ frame_sum,
+                                                            const float* __restrict__ initial_phase, int64_t n_frames_total,
+                                                            int Fr, int sr, int comb_mode, ScanOut out) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t fidx = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (fidx >= n_frames_total) return;
+    const uint32_t b = fidx / (uint32_t)Fr;
+    const int m = (int)(fidx - b * (uint32_t)Fr);
+    const float x0 = f0_frames[fidx];
+    const float x1 = (m + 1 < Fr) ? f0_frames[fidx + 1] : x0;
+    const float srf = (float)sr;
+    const double srd = PRECISE ? 1.0 / (double)sr : (double)sr;
+
+    double before = 0.0;                                  // the preceding frames of this utterance
+    for (int i = lane; i < m; i += 64) before += frame_sum[(int64_t)b * Fr + i];
+    before = wave_total_of_scan(wave_incl_scan_dpp(before));
+
+    const float wb = (float)lane * 0.015625f;
+    float fval[8];
+    double local[8];
+    double run = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        fval[i] = lerp_frame(x0, x1, wb + (float)i * 0.001953125f);
+        run += increment<PRECISE>(fval[i], srf, srd);
+        local[i] = run;
+    }
+    double base = before + (wave_incl_scan_dpp(run) - run);
+
+    float init_f = 0.f;
+    const bool has_init = initial_phase != nullptr;
+    if (has_init) {
+        const float ip = initial_phase[b];
+        if (PRECISE) base += (double)ip / 2.0 / 3.141592653589793;             // .to(fp64)/2/np.pi
+        init_f = __fdiv_rn(__fdiv_rn(ip, 2.0f), 3.14159274101257324f);        // fp32 /2 /np.pi
+    }
+    const float two_pi_f = 6.28318548202514648f, pi_f = 3.14159274101257324f;
+    const bool gated = comb_mode == DDSP_COMB_SINC_GATED;
+    float r_v[8], c_v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double S = base + local[i];
+        float r;
+        if (PRECISE) {
+            r = (float)(S - rint(S));
+        } else {
+            float Sf = (float)S;                           // ATen CPU cumsum: fp64 accumulator, fp32 output per element
+            if (has_init) Sf = __fadd_rn(Sf, init_f);
+            r = Sf - rintf(Sf);
+        }
+        r_v[i] = r;
+        // comb = sin(pi x) / (pi x), x = sr * rot / (f0 + 1e-3) (vocoder.py:539): see frame_scan_kernel for the evaluation
+        const float den = __fadd_rn(fval[i], 1e-3f);
+        const float num = __fmul_rn(srf, r);
+        const float rc = __builtin_amdgcn_rcpf(den);
+        float x = num * rc;
+        x = fmaf(fmaf(-den, x, num), rc, x);
+        const float xr = fmaf(-2.0f, rintf(0.5f * x), x);
+        const float t = fabsf(xr) > 0.5f ? copysignf(1.0f, xr) - xr : xr;
+        const float t2 = t * t;
+        float pl = 0.00046630281f;
+        pl = fmaf(pl, t2, -0.0073704309f);
+        pl = fmaf(pl, t2, 0.082145887f);
+        pl = fmaf(pl, t2, -0.59926453f);
+        pl = fmaf(pl, t2, 2.5501640f);
+        pl = fmaf(pl, t2, -5.1677128f);
+        pl = fmaf(pl, t2, 3.1415927f);
+        float c = (x == 0.0f) ? 1.0f : (t * pl) * __builtin_amdgcn_rcpf(pi_f * x);
+        if (gated && fval[i] <= 0.0f) c = 0.0f;
+        c_v[i] = c;
+    }
+    if (lane == 0) out.phase_frames[fidx] = __fmul_rn(two_pi_f, r_v[0]);
+    const int64_t t0 = (int64_t)fidx * 512 + lane * 8;
+    auto put = [&](float* dst, const float (&v)[8]) {
+        *(f32x4*)(dst + t0) = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)(dst + t0 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    };
+    if (out.comb) put(out.comb, c_v);
+    if (out.rot) put(out.rot, r_v);
+    if (out.f0_up) put(out.f0_up, fval);
+    if (out.phase) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r_v[i] = __fmul_rn(two_pi_f, r_v[i]);
+        put(out.phase, r_v);
     }
 }
 
@@ -253,7 +367,7 @@ extern "C" int ddsp_phase_scan(ddsp_ctx* ctx, void* stream, const float* f0_fram
                                float* phase, float* comb, float* f0_up, float* phase_frames) {
     DDSP_REQUIRE(ctx, ctx && f0_frames && phase_frames, "ddsp_phase_scan: null argument");
     DDSP_REQUIRE(ctx, B >= 0 && Fr >= 1 && hop >= 1 && hop <= 1024 && sr > 0, "ddsp_phase_scan: bad shape");
-    DDSP_REQUIRE(ctx, Fr * (int64_t)hop < (1 << 24), "ddsp_phase_scan: Fr*hop must stay below 2^24");
+    DDSP_REQUIRE(ctx, Fr * (int64_t)hop < (1 << 24) && B * Fr < (int64_t)1 << 31, "ddsp_phase_scan: Fr*hop must stay below 2^24, B*Fr below 2^31");
     DDSP_REQUIRE(ctx, comb_mode >= 0 && comb_mode <= 2, "ddsp_phase_scan: unknown comb_mode");
     DDSP_REQUIRE(ctx, (comb_mode == DDSP_COMB_NONE) == (comb == nullptr), "ddsp_phase_scan: comb buffer vs comb_mode");
     if (B == 0) return DDSP_OK;
@@ -271,19 +385,23 @@ extern "C" int ddsp_phase_scan(ddsp_ctx* ctx, void* stream, const float* f0_fram
     ScanOut o{rot, phase, comb, f0_up, phase_frames};
     ddsp_prof_begin(ctx, st, PF_PHASE_SCAN);
     const bool vec8 = hop == 512 && (((uintptr_t)rot | (uintptr_t)phase | (uintptr_t)comb | (uintptr_t)f0_up) % 16) == 0;
-#define DDSP_SCAN(P, V)                                                                                              \
-    hipLaunchKernelGGL((frame_scan_kernel<P, V>), dim3(blocks), dim3(256), 0, st, f0_frames, fsum, initial_phase, nf, \
-                       (int)Fr, hop, scale, sr, comb_mode, o)
-    if (precise) {
-        hipLaunchKernelGGL(frame_sum_kernel<true>, dim3(blocks), dim3(256), 0, st, f0_frames, nf, (int)Fr, hop, scale,
-                           sr, fsum);
-        if (vec8) DDSP_SCAN(true, true); else DDSP_SCAN(true, false);
+    if (vec8 && precise) {
+        hipLaunchKernelGGL(frame_sum512_kernel<true>, dim3(blocks), dim3(256), 0, st, f0_frames, nf, (int)Fr, sr, fsum);
+        hipLaunchKernelGGL(frame_scan512_kernel<true>, dim3(blocks), dim3(256), 0, st, f0_frames, fsum, initial_phase, nf, (int)Fr, sr,
+                           comb_mode, o);
+    } else if (vec8) {
+        hipLaunchKernelGGL(frame_sum512_kernel<false>, dim3(blocks), dim3(256), 0, st, f0_frames, nf, (int)Fr, sr, fsum);
+        hipLaunchKernelGGL(frame_scan512_kernel<false>, dim3(blocks), dim3(256), 0, st, f0_frames, fsum, initial_phase, nf, (int)Fr, sr,
+                           comb_mode, o);
+    } else if (precise) {
+        hipLaunchKernelGGL(frame_sum_kernel<true>, dim3(blocks), dim3(256), 0, st, f0_frames, nf, (int)Fr, hop, scale, sr, fsum);
+        hipLaunchKernelGGL(frame_scan_kernel<true>, dim3(blocks), dim3(256), 0, st, f0_frames, fsum, initial_phase, nf, (int)Fr, hop,
+                           scale, sr, comb_mode, o);
     } else {
-        hipLaunchKernelGGL(frame_sum_kernel<false>, dim3(blocks), dim3(256), 0, st, f0_frames, nf, (int)Fr, hop, scale,
-                           sr, fsum);
-        if (vec8) DDSP_SCAN(false, true); else DDSP_SCAN(false, false);
+        hipLaunchKernelGGL(frame_sum_kernel<false>, dim3(blocks), dim3(256), 0, st, f0_frames, nf, (int)Fr, hop, scale, sr, fsum);
+        hipLaunchKernelGGL(frame_scan_kernel<false>, dim3(blocks), dim3(256), 0, st, f0_frames, fsum, initial_phase, nf, (int)Fr, hop,
+                           scale, sr, comb_mode, o);
     }
-#undef DDSP_SCAN
     {
         const double outs = (rot ? 1 : 0) + (phase ? 1 : 0) + (comb ? 1 : 0) + (f0_up ? 1 : 0);
         ddsp_prof_end(ctx, st, 0.0, 4.0 * nf * (2.0 + outs * hop));
