@@ -29,3 +29,5 @@ void performer_kv(hipStream_t st, const float* k, const float* v, const float* P
 // attn (B*Fr, 512) from q (B*Fr, 512), P, ctxT, ks
 void performer_q(hipStream_t st, const float* q, const float* P, const float* ctxT, const float* ks, int B, int Fr,
                  float* attn);
+// causal linear attention in chunks of 16 frames (`c: true`, pcmer.py:170-188), inference: attn (B*Fr, 512) from q, k, v and P
+void performer_causal(hipStream_t st, const float* q, const float* k, const float* v, const float* P, int B, int Fr, float* attn);

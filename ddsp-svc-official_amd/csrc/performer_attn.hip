@@ -399,6 +399,220 @@ __global__ void __launch_bounds__(256, 4) performer_q_persist_kernel(const float
     }
 }
 
+// ---- causal linear attention in chunks (ddsp/pcmer.py:170-188, `c: true`; round 3) ---------------------------------------------
+// out_n = q'_n . S_n / (q'_n . (z_n + 1e-6)),  S_n = sum_{m<=n} k'_m (x) v_m,  z_n = sum_{m<=n} k'_m.  `fast_transformers.CausalDotProduct`
+// (the numerator) is a third-party CUDA extension that is not in the image: restated from its definition; the normaliser is the
+// reference's own code.  For a chunk of 16 frames:   out = [ Q' S_prev + tril(Q' K'^T) V ] / [ Q' (z_prev + 1e-6) + rowsum(tril(Q' K'^T)) ],
+// then S_prev += K'^T V, z_prev += colsum(K').  One workgroup (4 wavefronts) owns one (utterance, head) and walks its chunks;
+// every product runs on v_mfma_f32_16x16x4_f32:
+//   F  feature maps: wave w takes the 16-feature tiles w, w + 4, ... (its rows of dn*log2(e)*P stay in registers for the whole
+//      launch): dash = x P^T for x = q and k (frames x features), k' finished at once into the LDS, q' after the row maximum
+//      has been exchanged through the LDS;
+//   A  (K' Q'^T), kframes x qframes, the feature range cut over the four waves, partial tiles through the LDS;
+//   O  wave w owns channels 16w .. 16w + 15 of the output: out^T = V^T tril(A) (the summed, masked tile IS the operand: its
+//      accumulator layout has lane = qframe, register = kframe) + S^T Q'^T (S lives in this wave's accumulators, 17 tiles of
+//      16 features x 16 channels, and an accumulator register is again the k-slot the product wants); the denominators on the
+//      vector ALU from the same Q' registers;
+//   S  S += K'^T V for the wave's channels, z += column sums.
+// Nothing but q, k, v is read and the attention output written (the sequential kernel below read q', k' - 190 MB a layer - that a
+// GEMM and a row kernel had written).  All arithmetic fp32.
+constexpr int CC = 16;                  // frames per chunk
+constexpr int CPF = LDJ + 4;            // pitch of a q' / k' row in the LDS: 16-byte reads of 16 consecutive rows hit 16 different bank quads
+constexpr int CPD = DH + 4;             // pitch of a q / k / v row
+typedef float f32x4c __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+
+__global__ void __launch_bounds__(256, 2) performer_causal_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                  const float* __restrict__ v, const float* __restrict__ P, int Fr,
+                                                                  float* __restrict__ out) {
+    constexpr int MAXT = (NJT + 3) / 4;   // 5 feature tiles per wave at most
+    __shared__ float qs[CC * CPD], ks_[CC * CPD], vs[CC * CPD], Qf[CC * CPF], Kf[CC * CPF], ATp[4 * 256], z[LDJ], diagq[CC], diagk[CC],
+        pmax[4 * CC];
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, kq = lane >> 4;
+    // this wave's rows of the scaled projection matrix: tile c <-> features 16 (w + 4 c) + n, elements 16 kq .. 16 kq + 15
+    float pf[MAXT][16];
+#pragma unroll
+    for (int c = 0; c < MAXT; ++c) {
+        const int j = 16 * (w + 4 * c) + n;
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            f32x4c x = {0.f, 0.f, 0.f, 0.f};
+            if (j < NF) x = *(const f32x4c*)(P + (int64_t)j * DH + 16 * kq + 4 * e4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pf[c][4 * e4 + e] = PSCALE * x[e];
+        }
+    }
+    f32x4c S[NJT];                         // S[t][r] = S_state[feature 16 t + 4 kq + r][channel 16 w + n]
+#pragma unroll
+    for (int t = 0; t < NJT; ++t) S[t] = f32x4c{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < LDJ; i += 256) z[i] = 0.f;
+
+    // chunk staging: thread <-> 4 consecutive channels of one frame, for each of q, k, v
+    const int sf = tid >> 4, sc = 4 * (tid & 15);
+    const float* base = q + ((int64_t)b * Fr) * INNER + h * DH + sc;
+    const int64_t koff = k - q, voff = v - q;
+    f32x4c rq, rk, rv;
+    auto fetch = [&](int f0) {
+        const int f = f0 + sf;
+        rq = rk = rv = f32x4c{0.f, 0.f, 0.f, 0.f};
+        if (f < Fr) {
+            const float* src = base + (int64_t)f * INNER;
+            rq = *(const f32x4c*)src;
+            rk = *(const f32x4c*)(src + koff);
+            rv = *(const f32x4c*)(src + voff);
+        }
+    };
+    auto row_sum16 = [&](float x) {       // over the 16 lanes that share a frame
+        x += __shfl_xor(x, 1, 64);
+        x += __shfl_xor(x, 2, 64);
+        x += __shfl_xor(x, 4, 64);
+        x += __shfl_xor(x, 8, 64);
+        return x;
+    };
+    auto stage = [&]() {
+        *(f32x4c*)(qs + sf * CPD + sc) = rq;
+        *(f32x4c*)(ks_ + sf * CPD + sc) = rk;
+        *(f32x4c*)(vs + sf * CPD + sc) = rv;
+        const float dq = row_sum16(rq[0] * rq[0] + rq[1] * rq[1] + rq[2] * rq[2] + rq[3] * rq[3]);
+        const float dk = row_sum16(rk[0] * rk[0] + rk[1] * rk[1] + rk[2] * rk[2] + rk[3] * rk[3]);
+        if ((tid & 15) == 0) {
+            diagq[sf] = NEG_HALF * dq;    // -0.5 dn^2 |x|^2 in the base-2 domain
+            diagk[sf] = NEG_HALF * dk;
+        }
+    };
+    fetch(0);
+    stage();
+    __syncthreads();
+
+    for (int f0 = 0; f0 < Fr; f0 += CC) {
+        if (f0 + CC < Fr) fetch(f0 + CC);
+        // ---- F: dash = x P^T on the wave's feature tiles; k' finished, q' waits for the row maximum ----
+        float qa[16], ka[16];
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            const f32x4c a = *(const f32x4c*)(qs + n * CPD + 16 * kq + 4 * e4), c = *(const f32x4c*)(ks_ + n * CPD + 16 * kq + 4 * e4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                qa[4 * e4 + e] = a[e];
+                ka[4 * e4 + e] = c[e];
+            }
+        }
+        const f32x4c dgk = *(const f32x4c*)(diagk + 4 * kq), dgq = *(const f32x4c*)(diagq + 4 * kq);
+        f32x4c dq[MAXT];
+        f32x4c mx = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+        for (int c = 0; c < MAXT; ++c) {
+            const int t = w + 4 * c;
+            if (t < NJT) {
+                f32x4c dk = {0.f, 0.f, 0.f, 0.f};
+                dq[c] = f32x4c{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    dq[c] = MFMA16(qa[s], pf[c][s], dq[c]);
+                    dk = MFMA16(ka[s], pf[c][s], dk);
+                }
+                const bool feat_ok = 16 * t + n < NF;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = feat_ok && f0 + 4 * kq + r < Fr;
+                    Kf[(4 * kq + r) * CPF + 16 * t + n] = ok ? __builtin_amdgcn_exp2f(dk[r] + dgk[r] + KOFF) : 0.f;
+                    if (feat_ok) mx[r] = fmaxf(mx[r], dq[c][r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float m = mx[r];
+            m = fmaxf(m, __shfl_xor(m, 1, 64));
+            m = fmaxf(m, __shfl_xor(m, 2, 64));
+            m = fmaxf(m, __shfl_xor(m, 4, 64));
+            m = fmaxf(m, __shfl_xor(m, 8, 64));
+            mx[r] = m;
+        }
+        if (n == 0) *(f32x4c*)(pmax + w * CC + 4 * kq) = mx;
+        __syncthreads();
+        {
+            const f32x4c m0 = *(const f32x4c*)(pmax + 4 * kq), m1 = *(const f32x4c*)(pmax + CC + 4 * kq),
+                         m2 = *(const f32x4c*)(pmax + 2 * CC + 4 * kq), m3 = *(const f32x4c*)(pmax + 3 * CC + 4 * kq);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx[r] = dgq[r] - fmaxf(fmaxf(m0[r], m1[r]), fmaxf(m2[r], m3[r]));
+        }
+#pragma unroll
+        for (int c = 0; c < MAXT; ++c) {
+            const int t = w + 4 * c;
+            if (t < NJT) {
+                const bool feat_ok = 16 * t + n < NF;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Qf[(4 * kq + r) * CPF + 16 * t + n] = feat_ok ? RATIO * (__builtin_amdgcn_exp2f(dq[c][r] + mx[r]) + EPS) : 0.f;
+            }
+        }
+        __syncthreads();
+        // ---- A: this wave's share (68 features) of K' Q'^T ----
+        {
+            f32x4c at = {0.f, 0.f, 0.f, 0.f};
+            const float* kr = Kf + n * CPF + 68 * w + kq;
+            const float* qr = Qf + n * CPF + 68 * w + kq;
+#pragma unroll
+            for (int j = 0; j < 17; ++j) at = MFMA16(kr[4 * j], qr[4 * j], at);
+            *(f32x4c*)(ATp + w * 256 + lane * 4) = at;
+        }
+        __syncthreads();
+        // ---- O: out^T for channels 16 w .. 16 w + 15 ----
+        f32x4c o = {0.f, 0.f, 0.f, 0.f};
+        float den = 0.f;
+        {
+            f32x4c at = *(const f32x4c*)(ATp + lane * 4);
+#pragma unroll
+            for (int ww = 1; ww < 4; ++ww) at += *(const f32x4c*)(ATp + ww * 256 + lane * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                at[r] = 4 * kq + r <= n ? at[r] : 0.f;      // kframe <= qframe
+                den += at[r];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) o = MFMA16(vs[(4 * kq + s) * CPD + 16 * w + n], at[s], o);
+        }
+#pragma unroll
+        for (int t = 0; t < NJT; ++t) {
+            const f32x4c qv = *(const f32x4c*)(Qf + n * CPF + 16 * t + 4 * kq);
+            const f32x4c zv = *(const f32x4c*)(z + 16 * t + 4 * kq);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o = MFMA16(S[t][r], qv[r], o);
+                den = fmaf(qv[r], zv[r] + 1e-6f, den);
+            }
+        }
+        den += __shfl_xor(den, 16, 64);
+        den += __shfl_xor(den, 32, 64);
+        if (f0 + n < Fr) {
+            const float inv = 1.0f / den;
+            *(f32x4c*)(out + ((int64_t)b * Fr + f0 + n) * INNER + h * DH + 16 * w + 4 * kq) = o * inv;
+        }
+        __syncthreads();               // every wave is done with z (and with q', whose buffer the next chunk rewrites)
+        // ---- S: state update for this wave's channels ----
+        {
+            float vb[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) vb[s] = vs[(4 * s + kq) * CPD + 16 * w + n];
+#pragma unroll
+            for (int t = 0; t < NJT; ++t)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) S[t] = MFMA16(Kf[(4 * s + kq) * CPF + 16 * t + n], vb[s], S[t]);
+            for (int i = tid; i < LDJ; i += 256) {
+                float a = 0.f;
+#pragma unroll
+                for (int f = 0; f < CC; ++f) a += Kf[f * CPF + i];
+                z[i] += a;
+            }
+        }
+        __syncthreads();               // k', v of this chunk are dead
+        if (f0 + CC < Fr) stage();
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 // measurement switch: DDSP_ATTN_PERSIST=1 runs the persistent variants (a device counter per launch, zeroed on the stream)
@@ -444,4 +658,9 @@ void performer_q(hipStream_t st, const float* q, const float* P, const float* ct
         return;
     }
     hipLaunchKernelGGL(performer_q_kernel, dim3((unsigned)(n_grp * B * H)), dim3(256), 0, st, q, P, ctxT, ks, Fr, n_grp, attn);
+}
+
+// chunked causal attention (inference): attn (B*Fr, 512) from q, k, v (B*Fr, 512) and P (266, 64)
+void performer_causal(hipStream_t st, const float* q, const float* k, const float* v, const float* P, int B, int Fr, float* attn) {
+    hipLaunchKernelGGL(performer_causal_kernel, dim3((unsigned)(B * H)), dim3(256), 0, st, q, k, v, P, Fr, attn);
 }

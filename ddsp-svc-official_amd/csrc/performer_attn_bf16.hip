@@ -998,6 +998,15 @@ extern "C" int ddsp_performer_attention(ddsp_ctx* ctx, void* stream, const float
                                         const float* proj, int64_t B, int64_t Fr, float* out, int math) {
     DDSP_REQUIRE(ctx, ctx && q && k && v && proj && out, "ddsp_performer_attention: null argument");
     DDSP_REQUIRE(ctx, B >= 1 && B <= 4096 && Fr >= 1 && B * Fr < (1 << 26), "ddsp_performer_attention: bad shape");
+    if (math == DDSP_ATTENTION_CAUSAL) {     // the causal network's attention (`c: true`): chunked kernel, fp32 products
+        hipStream_t stc = (hipStream_t)stream;
+        DDSP_ENTER_DEVICE(ctx);
+        ddsp_prof_begin(ctx, stc, PF_U2C_GEMM_ATTNOUT);
+        performer_causal(stc, q, k, v, proj, (int)B, (int)Fr, out);
+        ddsp_prof_end(ctx, stc, 10.0 * B * Fr * H * NF * DH, 4.0 * B * Fr * 4 * INNER);
+        DDSP_LAUNCH_CHECK(ctx);
+        return DDSP_OK;
+    }
     // (math = 100 + ablation mask: measurement aid of tools/attn_ablate.py, results are meaningless)
     const int ablate = math >= 100 ? math - 100 : 0;
     const bool want_pair = math >= 100;      // 100 + mask: the round-2 kernel pair (mask 0: nothing switched off)

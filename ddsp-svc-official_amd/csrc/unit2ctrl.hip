@@ -558,6 +558,16 @@ __global__ void __launch_bounds__(256) attn_denominator_kernel(const float* __re
     if (lane == 0) dinv[r] = 1.0f / (s + 1e-8f);
 }
 
+// DDSP_CAUSAL_CHUNKED=0: the causal network's inference attention on the sequential kernel below (measurement aid)
+static bool causal_chunked() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("DDSP_CAUSAL_CHUNKED");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 // ---- causal linear attention (ddsp/pcmer.py:170-188, `c: true`), inference ---------------------------------------------------
 // out[n] = (q'_n . sum_{m<=n} k'_m (x) v_m) / (q'_n . (sum_{m<=n} k'_m + 1e-6)).  One workgroup per (utterance, head) walks
 // the frames in order; thread t owns channel e = t & 63 of rows j = (t >> 6) + 4 i of the running 266 x 64 state (67 registers).
@@ -1809,8 +1819,12 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
                 PROF(PF_U2C_GEMM_ATTNOUT, 4.0 * M8 * NF * DH, 4.0 * M * 2 * INNER,
                      performer_q_bf16(st, b.q, p3, b.cx, b.ks, (int)B, (int)Fr, b.attn, 0, asplit));
             }
+        } else if (w.causal && !b.pre && causal_chunked()) {
+            // causal mode, inference: chunked linear attention in one kernel (performer_attn.hip); q' / k' never reach HBM
+            PROF(PF_U2C_GEMM_ATTNOUT, 2.0 * M8 * (3.0 * NF * DH + 16.0 * (NF + DH)) + 4.0 * M8 * NF * DH, 4.0 * M * 4 * INNER,
+                 performer_causal(st, b.q, b.k, b.v, L.proj, (int)B, (int)Fr, b.attn));
         } else if (w.causal) {
-            // causal mode: feature maps through the GEMM + row kernels of the training path (q', k' stay in the arena for the
+            // causal mode, training forward: feature maps through the GEMM + row kernels (q', k' stay in the arena for the
             // backward pass), then the sequential causal attention kernel
             gemm::Args g = gemm::make(b.q, DH, L.proj, DH, (int)M8, NF, DH);
             gemm::EpiStore e{b.qf, LDF, nullptr, 1, 0, 0};

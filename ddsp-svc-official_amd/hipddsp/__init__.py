@@ -20,6 +20,7 @@ FIR_ALLPASS, FIR_DYNAMIC, FIR_STATIC = 0, 1, 2
 EXC_AUDIO, EXC_UNIT_NOISE, EXC_GENERATE = 0, 1, 2
 FIR_FP32, FIR_SPLIT_BF16 = 0, 3   # ddsp_ltv_fir `math` (include/ddsp_amd.h)
 MATH_FP32, MATH_SPLIT_BF16 = 0, 3  # ddsp_ctx_set_math
+ATTENTION_CAUSAL = 200            # ddsp_performer_attention: causal_linear_attention (pcmer.py:170-188)
 
 _c = ctypes
 _vp, _i64, _u64, _int, _f32, _f64 = _c.c_void_p, _c.c_int64, _c.c_uint64, _c.c_int, _c.c_float, _c.c_double

@@ -351,7 +351,10 @@ int ddsp_gemm_f32(ddsp_ctx* ctx, void* stream, const float* A, int64_t lda, int 
  * (B*Fr, 512) = 8 heads x 64, proj (266, 64) the layer's `projection_matrix`; out (B*Fr, 512) = the merged heads before
  * `to_out`.  math: DDSP_MATH_FP32 (fp32 matrix products) or DDSP_MATH_SPLIT_BF16 (the feature projections from six bf16
  * piece products - they enter an exponential -, the two context products from three).  Exposed for unit tests of the
- * kernels ddsp_unit2ctrl_fwd runs at inference (it picks the split kernels from 32 utterances on). */
+ * kernels ddsp_unit2ctrl_fwd runs at inference (it picks the split kernels from 32 utterances on).
+ * math = DDSP_ATTENTION_CAUSAL: `causal_linear_attention` (pcmer.py:170-188, `c: true` networks) instead - the running sums
+ * over the frames up to and including each one, as chunked products with fp32 arithmetic. */
+#define DDSP_ATTENTION_CAUSAL 200
 int ddsp_performer_attention(ddsp_ctx* ctx, void* stream, const float* q, const float* k, const float* v,
                              const float* proj, int64_t B, int64_t Fr, float* out, int math);
 

@@ -55,6 +55,44 @@ def test_attention_against_fp64(ctx, dev, B, Fr, math):
     assert err < (2e-6 if math == 0 else 1e-5), err
 
 
+def causal_reference(q, k, v, P, B, Fr):
+    """fp64 restatement of `softmax_kernel` + `causal_linear_attention` (pcmer.py:170-188; `CausalDotProduct` by its
+    definition: out_n = q'_n . sum_{m<=n} k'_m (x) v_m)."""
+    q, k, v, P = (t.double() for t in (q, k, v, P))
+    sp = lambda x: x.reshape(B, Fr, H, DH).permute(0, 2, 1, 3)
+    q, k, v = sp(q), sp(k), sp(v)
+    dn, ratio, eps = DH ** -0.25, NF ** -0.5, 1e-4
+    dq, dk = dn * q @ P.t(), dn * k @ P.t()
+    qf = ratio * (torch.exp(dq - (q ** 2).sum(-1, keepdim=True) * 0.5 * dn ** 2 - dq.amax(dim=-1, keepdim=True)) + eps)
+    kf = ratio * torch.exp(dk - (k ** 2).sum(-1, keepdim=True) * 0.5 * dn ** 2 + eps)
+    dinv = 1.0 / torch.einsum("bhnd,bhnd->bhn", qf, kf.cumsum(dim=-2) + 1e-6)
+    A = torch.tril(qf @ kf.transpose(-1, -2))                             # (B, H, Fr, Fr)
+    out = (A @ v) * dinv.unsqueeze(-1)
+    return out.permute(0, 2, 1, 3).reshape(B * Fr, H * DH)
+
+
+# frame counts around the 16-frame chunks of the kernel: one partial chunk, exact multiples, the bench's 172, long clips
+@pytest.mark.parametrize("B,Fr", [(1, 1), (2, 15), (3, 16), (2, 17), (1, 87), (8, 172), (4, 400), (64, 32)])
+def test_causal_attention_against_fp64(ctx, dev, B, Fr):
+    import hipddsp
+    q, k, v, P = make(3 * B + Fr, B, Fr, 1.0, dev)
+    want = causal_reference(q, k, v, P, B, Fr)
+    got = ctx.performer_attention(q, k, v, P, B, Fr, math=hipddsp.ATTENTION_CAUSAL)
+    assert torch.isfinite(got).all()
+    err = float((got.double() - want).norm() / want.norm())
+    assert err < 3e-6, err
+    # causality itself: changing the last frames leaves every earlier output bit for bit as it was
+    if Fr > 20:
+        q2, k2, v2 = q.clone(), k.clone(), v.clone()
+        rows = torch.arange(B, device=dev)[:, None] * Fr + torch.arange(Fr - 5, Fr, device=dev)[None]
+        for t in (q2, k2, v2):
+            t[rows.reshape(-1)] += 1.0
+        got2 = ctx.performer_attention(q2, k2, v2, P, B, Fr, math=hipddsp.ATTENTION_CAUSAL)
+        keep = torch.ones(B * Fr, dtype=torch.bool, device=dev)
+        keep[rows.reshape(-1)] = False
+        assert torch.equal(got[keep], got2[keep])
+
+
 @pytest.mark.parametrize("math", [0, 3])
 def test_attention_large_exponents(ctx, dev, math):
     """Keys and queries scaled so that the projected exponents reach |dn x.P| ~ 20: the error of the projection product

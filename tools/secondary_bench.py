@@ -101,7 +101,7 @@ for L in (860, 172):
     mel, ef0 = mel.to(dev), ef0.to(dev)
     t = timeit(lambda: gen(mel, ef0, rand_ini=ri[0]), n=10)
     out[f"enhancer_generator_{L}_frames"] = {"ms": t * 1e3, "x_realtime": L * 512 / 44100 / t, "tflops_algorithmic": 0.627e-3 * L / t}
-# the causal network (c: true) at the bench batch - sequential attention scans, correct-first
+# the causal network (c: true) at the bench batch - chunked causal linear attention (performer_causal_kernel)
 from ddsp.vocoder import CombSub
 mc = CombSub(44100, 512, cfg["n_mag_allpass"], cfg["n_mag_harmonic"], cfg["n_mag_noise"], 256, cfg["n_spk"], c=True)
 mc.load_state_dict(model64.state_dict(), strict=True)
