@@ -2350,6 +2350,15 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
         if ((rc = layer_grads(ctx, st, dX, D, D, b.attn, INNER, INNER, 1, (int)Fr, M, wpart, cpart, xs, GLP(out_w), INNER,
                               GLP(out_b)))) return rc;
         dgrad(st, dX, D, L.out_w, D, INNER, M, dB512, false, wt_out[l]);                                       // d_attn
+        // the two K = 64 adjoint products of the attention (both operands K-contiguous, one problem per (utterance, head)): on the
+        // LDS-DMA kernel in the context's arithmetic (round 3; the register-staged fp32 kernel took 51 us each at B = 32)
+        auto attn_k64 = [&](hipStream_t s_, gemm::Args g, int batch, const EpiRowOuter& e) {
+            if (ctx->math != DDSP_MATH_FP32 && gemm::dma_ok(g)) {
+                g.math = DDSP_MATH_SPLIT_BF16;
+                gemm::dma_go<64, 64, EpiRowOuter, 3, 4>(s_, g, batch, e);
+            } else
+                gemm::launch_tile<64, 64, true, true, gemm::A_PLAIN>(s_, g, batch, e);
+        };
         if (w.causal) {
             // causal attention: three sequential scans per (utterance, head) (dD / coefq hold 1/den and d den between them)
             hipLaunchKernelGGL(causal_attn_bwd_q_kernel, dim3((unsigned)(B * H)), dim3(320), 0, st, b.qf, b.kf, b.v, dB512, b.attn,
@@ -2368,7 +2377,7 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
                 g.sB_hi = (int64_t)H * NF * DH;
                 g.sB_lo = (int64_t)NF * DH;
                 EpiRowOuter e{dQF, dD, b.ks, (int)Fr};
-                gemm::launch_tile<64, 64, true, true, gemm::A_PLAIN>(st, g, (int)(B * H), e);
+                attn_k64(st, g, (int)(B * H), e);
             }
             {   // d_ctx = q'^T d_num
                 gemm::Args g = gemm::make(b.qf, (int64_t)H * LDF, dB512, INNER, NF, DH, (int)Fr);
@@ -2389,7 +2398,7 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
                 g.sB_hi = (int64_t)H * NF * DH;
                 g.sB_lo = (int64_t)NF * DH;
                 EpiRowOuter e{dKF, nullptr, dks, (int)Fr};
-                gemm::launch_tile<64, 64, true, true, gemm::A_PLAIN>(st, g, (int)(B * H), e);
+                attn_k64(st, g, (int)(B * H), e);
             }
             {   // d_v = k' d_ctx
                 gemm::Args g = gemm::make(b.kf, (int64_t)H * LDF, dcx, DH, (int)Fr, DH, NF);
