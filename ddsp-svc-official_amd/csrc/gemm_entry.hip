@@ -1,5 +1,6 @@
 // Plain GEMM entry point of the fp32-MFMA kernel: unit tests of the building block and tile/schedule A/B timing.
 #include "gemm_ws.h"
+#include "gemm_ln.h"
 
 extern "C" int ddsp_gemm_f32(ddsp_ctx* ctx, void* stream, const float* A, int64_t lda, int a_k_contig, const float* B,
                              int64_t ldb, int b_k_contig, const float* bias, float* C, int64_t ldc, int M, int N, int K,
@@ -117,6 +118,23 @@ extern "C" int ddsp_gemm_f32(ddsp_ctx* ctx, void* stream, const float* A, int64_
         TILE(false, true)
     }
     ddsp_prof_end(ctx, st, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    DDSP_LAUNCH_CHECK(ctx);
+    return DDSP_OK;
+}
+
+// x = res + A W^T + bias (M x 256) and y = LayerNorm(x) * gamma + beta in one launch (gemm_ln.h); A (M x K) and W (256 x K) in
+// the pre-split operand layout.  The building block ddsp_unit2ctrl_fwd runs for its out-projection / pw2 layers at large batches.
+extern "C" int ddsp_gemm_res_ln(ddsp_ctx* ctx, void* stream, const float* A_split, const float* W_split, const float* bias,
+                                const float* res, const float* gamma, const float* beta, int M, int K, float* X, float* Y,
+                                int y_split) {
+    DDSP_REQUIRE(ctx, ctx && A_split && W_split && bias && res && gamma && beta && X && Y, "ddsp_gemm_res_ln: null argument");
+    gemm::LnArgs a{A_split, W_split, K, K, M, K, bias, res, X, gamma, beta, Y, y_split ? 1 : 0};
+    DDSP_REQUIRE(ctx, M >= 1 && K >= 64 && gemm::res_ln_ok(a), "ddsp_gemm_res_ln: K % 32 == 0, K >= 64, 16-byte aligned operands");
+    hipStream_t st = (hipStream_t)stream;
+    DDSP_ENTER_DEVICE(ctx);
+    ddsp_prof_begin(ctx, st, PF_OTHER);
+    DDSP_HIP(ctx, gemm::launch_res_ln(st, a));
+    ddsp_prof_end(ctx, st, 2.0 * M * 256.0 * K, 4.0 * M * (K + 4.0 * 256));
     DDSP_LAUNCH_CHECK(ctx);
     return DDSP_OK;
 }

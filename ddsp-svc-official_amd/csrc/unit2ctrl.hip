@@ -12,6 +12,7 @@
 // weight-norm) is small fused elementwise / row-reduction kernels.
 #include "gemm_f32.h"
 #include "gemm_ws.h"
+#include "gemm_ln.h"
 #include "wgrad_bf16.h"
 #include "performer_attn.h"
 
@@ -1670,6 +1671,22 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e);
         return (const float*)x_dst;
     };
+    // Large batches with pre-split operands: the residual layer AND the LayerNorm that follows it in one kernel (gemm_ln.h: a
+    // workgroup owns 64 rows x all 256 columns; same bits as the two launches).  DDSP_GEMM_LN=0 restores the pair.
+    static int gemm_ln_on = -1;
+    if (gemm_ln_on < 0) {
+        const char* e = getenv("DDSP_GEMM_LN");
+        gemm_ln_on = (e && e[0] == '0') ? 0 : 1;
+    }
+    bool ln_done = false;   // the next LayerNorm's output has been written by the producer of its input
+    auto ln_args = [&](const gemm::Args& g, const float* x_res, float* x_dst, const float* bias, const float* gamma,
+                       const float* beta, float* y_out) {
+        return gemm::LnArgs{g.A, g.B_split, g.lda, g.ldb, g.M, g.K, bias, x_res, x_dst, gamma, beta, y_out, 1};
+    };
+    auto ln_fusable = [&](const gemm::Args& g, const gemm::LnArgs& a) {
+        return gemm_ln_on && !ksplit && !bf.l[0].pre && g.math == DDSP_MATH_SPLIT_BF16 && g.B_split && g.A_split && asplit &&
+               g.N == D && M >= 2048 && gemm::res_ln_ok(a);
+    };
     {   // weight preparation, one launch (u2c_prepare_kernel)
         PrepArgs pa;
         pa.w = w;
@@ -1789,8 +1806,10 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         const ddsp_u2c_layer& L = w.layer[l];
         LayerBufs& b = bf.l[l];
         // -- x_mid = x_in + to_out(linear_attention(LN(x_in)))
-        PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
-             hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, ln_src ? ln_src : b.x_in, L.norm_w, L.norm_b, M, b.y, asplit, pending));
+        if (!ln_done)
+            PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
+                 hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, ln_src ? ln_src : b.x_in, L.norm_w, L.norm_b, M, b.y, asplit, pending));
+        ln_done = false;
         pending = LnPending{nullptr, nullptr, nullptr, 0};
         {
             gemm::Args g = gemm::make(b.y, D, bf.wqkv + (size_t)l * 3 * INNER * D, D, iM, 3 * INNER, D);
@@ -1889,11 +1908,19 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         {
             gemm::Args g = gemm::make(b.attn, INNER, L.out_w, INNER, iM, D, INNER);
             set_b(g, bf.wout + (size_t)l * D * INNER, attn_bf16 ? asplit : 0);
-            PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * D * INNER, 4.0 * M * (INNER + 2 * D), ln_src = residual_gemm(g, b.x_in, b.x_mid, L.out_b));
+            const gemm::LnArgs la = ln_args(g, b.x_in, b.x_mid, L.out_b, L.cm_ln_w, L.cm_ln_b, b.y2);
+            if (ln_fusable(g, la)) {
+                PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * D * INNER, 4.0 * M * (INNER + 4 * D), DDSP_HIP(ctx, gemm::launch_res_ln(st, la)));
+                ln_done = true;
+                ln_src = b.x_mid;
+            } else
+                PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * D * INNER, 4.0 * M * (INNER + 2 * D), ln_src = residual_gemm(g, b.x_in, b.x_mid, L.out_b));
         }
         // -- x_out = x_mid + conv_module(x_mid)
-        PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
-             hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, ln_src, L.cm_ln_w, L.cm_ln_b, M, b.y2, asplit, pending));
+        if (!ln_done)
+            PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
+                 hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, ln_src, L.cm_ln_w, L.cm_ln_b, M, b.y2, asplit, pending));
+        ln_done = false;
         pending = LnPending{nullptr, nullptr, nullptr, 0};
         if (fuse_glu) {
             gemm::Args g = gemm::make(b.y2, D, bf.wglu + (size_t)l * 2 * INNER * D, D, iM, 2 * INNER, D);
@@ -1939,14 +1966,25 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         {
             gemm::Args g = gemm::make(b.dwo, INNER, L.cm_pw2_w, INNER, iM, D, INNER);
             set_b(g, bf.wpw2 + (size_t)l * D * INNER, asplit);
-            PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * D * INNER, 4.0 * M * (INNER + 2 * D), ln_src = residual_gemm(g, b.x_mid, b.x_out, L.cm_pw2_b));
+            // (the LayerNorm behind pw2 is the next layer's, or the final one)
+            const float* n_g = l + 1 < 3 ? w.layer[l + 1].norm_w : w.final_ln_w;
+            const float* n_b = l + 1 < 3 ? w.layer[l + 1].norm_b : w.final_ln_b;
+            float* n_y = l + 1 < 3 ? bf.l[l + 1].y : bf.y_final;
+            const gemm::LnArgs la = ln_args(g, b.x_mid, b.x_out, L.cm_pw2_b, n_g, n_b, n_y);
+            if (ln_fusable(g, la)) {
+                PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * D * INNER, 4.0 * M * (INNER + 4 * D), DDSP_HIP(ctx, gemm::launch_res_ln(st, la)));
+                ln_done = true;
+                ln_src = b.x_out;
+            } else
+                PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * D * INNER, 4.0 * M * (INNER + 2 * D), ln_src = residual_gemm(g, b.x_mid, b.x_out, L.cm_pw2_b));
         }
         DDSP_LAUNCH_CHECK(ctx);
     }
     // ---- LayerNorm -> weight-normed head ----
-    PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
-         hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, ln_src, w.final_ln_w, w.final_ln_b,
-                            M, bf.y_final, asplit, pending));
+    if (!ln_done)
+        PROF(PF_U2C_ROWWISE, 0, 8.0 * M * D,
+             hipLaunchKernelGGL(layernorm_kernel, dim3(rows_g), dim3(256), 0, st, ln_src, w.final_ln_w, w.final_ln_b,
+                                M, bf.y_final, asplit, pending));
     {
         gemm::Args g = gemm::make(bf.y_final, D, bf.wh, D, iM, w.n_out, D);
         set_b(g, bf.wh, asplit);

@@ -90,6 +90,7 @@ SIGNATURES = {
     "ddsp_phase_vocoder": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
     "ddsp_volume_extract": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp]),
     "ddsp_align_units": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp]),
+    "ddsp_gemm_res_ln": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _int]),
     "ddsp_conv1d_pair_supported": (_int, [_vp, _int, _int, _int]),
     "ddsp_conv1d_pair": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _f32, _vp, _vp]),
     "ddsp_retime_f0": (_int, [_vp, _vp, _vp, _i64, _f64, _f64, _f32, _f64, _i64, _vp]),
@@ -467,6 +468,15 @@ class Context:
                   _ptr(residual), _ptr(out), _ptr(act), float(act_slope if act_slope is not None else 1.0), _ptr(w_split),
                   (CONV_X_SPLIT if x_split else 0) | (CONV_ACT_SPLIT if act_split else 0))
         return out if act_slope is None else (out, act)
+
+    def gemm_res_ln(self, A_split, W_split, bias, res, gamma, beta, y_split=True):
+        """X = res + A W^T + bias and Y = LayerNorm(X) * gamma + beta in one launch; A (M, K) and W (256, K) pre-split."""
+        M, K = A_split.shape
+        X = torch.empty(M, 256, device=A_split.device, dtype=torch.float32)
+        Y = torch.empty(M, 256, device=A_split.device, dtype=torch.float32)
+        self.call("ddsp_gemm_res_ln", _ptr(A_split), _ptr(W_split), _ptr(bias), _ptr(res), _ptr(gamma), _ptr(beta), int(M), int(K),
+                  _ptr(X), _ptr(Y), 1 if y_split else 0)
+        return X, Y
 
     def conv1d_pair_supported(self, C, ktaps, dil):
         return bool(self.lib.ddsp_conv1d_pair_supported(self.handle, int(C), int(ktaps), int(dil)))

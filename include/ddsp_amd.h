@@ -346,6 +346,14 @@ int ddsp_gemm_f32(ddsp_ctx* ctx, void* stream, const float* A, int64_t lda, int 
                   int64_t ldb, int b_k_contig, const float* bias, float* C, int64_t ldc, int M, int N, int K, int tile,
                   int variant);
 
+/* The fused building block of the control network's residual Linear layers (pcmer.py:221-251 `to_out`, :42-63 pw2) at large
+ * batches: X = res + A W^T + bias (M x 256; X may be res) and Y = LayerNorm(X) * gamma + beta (eps 1e-5) in one launch.
+ * A (M x K) and W (256 x K) are in the pre-split operand layout (per 8 consecutive k: 8 bf16 hi, then 8 bf16 lo); Y is
+ * written in that layout too (y_split != 0) or as fp32.  Same bits as ddsp_gemm_f32 on split operands followed by the
+ * LayerNorm kernel.  Exposed for tests. */
+int ddsp_gemm_res_ln(ddsp_ctx* ctx, void* stream, const float* A_split, const float* W_split, const float* bias,
+                     const float* res, const float* gamma, const float* beta, int M, int K, float* X, float* Y, int y_split);
+
 /* ---- building block: the linear attention of one PCmer layer without its Linear layers ------------------------------ */
 /* replaces ddsp/pcmer.py:69-77,123-159 (`softmax_kernel` feature maps + `linear_attention`, non-causal): q, k, v
  * (B*Fr, 512) = 8 heads x 64, proj (266, 64) the layer's `projection_matrix`; out (B*Fr, 512) = the merged heads before

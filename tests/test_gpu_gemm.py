@@ -96,3 +96,72 @@ def test_wave_specialised_kernel_rejects_short_k(ctx, dev):
     A, B = _mk((256, 128), 7, dev), _mk((128, 128), 8, dev)
     with pytest.raises(ValueError):
         ctx.gemm(A, B, tile=70)        # K < 256: a tile's epilogue rides in eight k-steps of the next
+
+
+# ---- residual Linear layer + LayerNorm in one kernel (csrc/gemm_ln.h) ---------------------------------------------------
+def _split_layout(X):
+    """(rows, K) fp32 -> the pre-split operand layout (per 8 k: 8 bf16 hi | 8 bf16 lo, lo = bf16(x - hi)) as a (rows, K) float
+    tensor, and the values hi + lo it encodes."""
+    hi = X.to(torch.bfloat16)
+    lo = (X - hi.float()).to(torch.bfloat16)
+    g = lambda t: t.view(torch.int16).view(X.shape[0], X.shape[1] // 8, 8)
+    packed = torch.cat([g(hi), g(lo)], dim=2).reshape(X.shape[0], -1).view(torch.float32).contiguous()
+    return packed, hi.double() + lo.double()
+
+
+def _unsplit(Y):
+    """the inverse for an output written in that layout: (rows, N) floats -> hi + lo as fp64."""
+    w = Y.contiguous().view(torch.int16).view(Y.shape[0], Y.shape[1] // 8, 16)
+    hi, lo = w[:, :, :8].contiguous().view(torch.bfloat16), w[:, :, 8:].contiguous().view(torch.bfloat16)
+    return (hi.double() + lo.double()).reshape(Y.shape[0], -1)
+
+
+@pytest.mark.parametrize("M,K", [(11008, 512), (1, 64), (63, 512), (64, 96), (65, 512), (1000, 256), (4100, 1024)])
+def test_residual_layernorm_kernel(ctx, dev, M, K):
+    """x = res + A W^T + b and LayerNorm(x) from ONE launch: against fp64 on the values the split operands encode, ragged row
+    counts around the 64-row workgroup tile, both output forms; x bit-identical to the LDS-DMA GEMM on the same operands."""
+    A, W = _mk((M, K), 21, dev), _mk((256, K), 22, dev) / K ** 0.5
+    bias, res, gamma, beta = _mk((256,), 23, dev), _mk((M, 256), 24, dev), _mk((256,), 25, dev), _mk((256,), 26, dev)
+    As, Av = _split_layout(A)
+    Ws, Wv = _split_layout(W)
+    X, Y = ctx.gemm_res_ln(As, Ws, bias, res, gamma, beta, y_split=True)
+    X2, Y2 = ctx.gemm_res_ln(As, Ws, bias, res, gamma, beta, y_split=False)
+    want = res.double() + Av @ Wv.t() + bias.double()
+    # three of the four piece products are kept: |error| <= 2^-16 |a||w| summed over K
+    assert float((X.double() - want).abs().max()) < 3e-5 * max(1.0, float(want.abs().max()))
+    assert torch.equal(X, X2)
+    mu = X.double().mean(dim=1, keepdim=True)
+    var = ((X.double() - mu) ** 2).mean(dim=1, keepdim=True)
+    ln = (X.double() - mu) / torch.sqrt(var + 1e-5) * gamma.double() + beta.double()
+    assert float((Y2.double() - ln).abs().max()) < 2e-5 * max(1.0, float(ln.abs().max()))
+    # the split form encodes the fp32 result to 16 mantissa bits
+    assert float((_unsplit(Y) - Y2.double()).abs().max()) < 2.0 ** -15 * max(1.0, float(Y2.abs().max()))
+    for _ in range(2):
+        X3, Y3 = ctx.gemm_res_ln(As, Ws, bias, res, gamma, beta, y_split=True)
+        assert torch.equal(X3, X) and torch.equal(Y3, Y)
+    if K >= 32 * 13:     # (the wave-specialised kernel's residual form, itself bit-identical to kernel_dma: needs 13 k-steps)
+        assert torch.equal(ctx.gemm(As, Ws, bias, tile=75, variant=8 + 16, out=res.clone()), X)
+
+
+def test_residual_layernorm_in_the_model_is_bit_identical(dev, lib_path):
+    """The control matrix of a B = 32 forward with the fused kernel equals, bit for bit, the one with the GEMM and LayerNorm
+    launched apart (DDSP_GEMM_LN=0; child processes, the switch is read once)."""
+    import subprocess, sys, os, hashlib
+    code = (
+        "import sys, os, hashlib; sys.path.insert(0, os.path.join(%r, 'ddsp-svc-official_amd'));"
+        "import torch, hipddsp, synthetic;"
+        "dev = torch.device('cuda:0');"
+        "model, cfg = synthetic.build_model('CombSub', seed=5, device=dev);"
+        "inp = {k: v.to(dev) for k, v in synthetic.make_inputs(11, 32, 172, with_noise=False).items()};"
+        "ctx = hipddsp.context_for(dev);"
+        "ps = ctx.phase_scan(inp['f0'], 512, 44100);"
+        "ctrl = model.unit2ctrl.forward_flat(inp['units'], inp['f0'], ps['phase_frames'], inp['volume'], inp['spk_id'], None);"
+        "print(hashlib.sha256(ctrl.cpu().numpy().tobytes()).hexdigest())"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, DDSP_GEMM_LN=flag)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append(out.stdout.strip().splitlines()[-1])
+    assert digests[0] == digests[1], digests
