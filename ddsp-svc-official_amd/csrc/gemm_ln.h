@@ -20,6 +20,7 @@
 #include "gemm_f32.h"
 
 #include <atomic>
+#include <stdlib.h>
 
 namespace gemm {
 
@@ -41,25 +42,27 @@ constexpr int LN_BM = 64, LN_N = 256, LN_NS = 4;   // 4 x 40 KB = the whole LDS:
 constexpr int LN_STAGE = (LN_BM + LN_N) * 32;                 // floats per stage: 40 KB
 constexpr size_t LN_LDS_BYTES = (size_t)LN_NS * LN_STAGE * sizeof(float);
 
-template <int NS>   // ring stages (a template also keeps the kernel out of the one-definition trouble of a header)
-__global__ void __launch_bounds__(1024) kernel_res_ln(LnArgs g) {
+template <int NS, int RB>   // NS ring stages; RB row blocks of 32 per wave: 1 = 16 waves (2 x 8 grid), 2 = 8 waves (each both row blocks)
+__global__ void __launch_bounds__(1024 / RB) kernel_res_ln(LnArgs g) {
     extern __shared__ __attribute__((aligned(1024))) float ln_lds[];
     float* const lds = ln_lds;
+    constexpr int NWAVE = 16 / RB;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rg = wave >> 3, cg = wave & 7, lr = lane & 31, lh = lane >> 5;
+    const int rg0 = RB == 1 ? wave >> 3 : 0, cg = wave & 7, lr = lane & 31, lh = lane >> 5;
     const int nk = g.K / 32;
     const int m0 = blockIdx.x * LN_BM;
-    const int row_m = m0 + 32 * rg + lr;                       // this lane's output row
-    const bool row_ok = row_m < g.M;
 
     // the residual rows first: they are the oldest vector-memory operations of the wave, so the ring's vmcnt waits cover them
-    f32x4 res[4];
+    f32x4 res[RB][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        res[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (row_ok) res[q] = *(const f32x4*)(g.res + (int64_t)row_m * LN_N + 32 * cg + 8 * q + 4 * lh);
+    for (int b = 0; b < RB; ++b) {
+        const int row_m = m0 + 32 * (rg0 + b) + lr;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            res[b][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row_m < g.M) res[b][q] = *(const f32x4*)(g.res + (int64_t)row_m * LN_N + 32 * cg + 8 * q + 4 * lh);
+        }
     }
-
     f32x4 bias4[4], gam4[4], bet4[4];   // (loaded now: one workgroup per CU, nothing would hide their latency in the epilogue)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -69,11 +72,13 @@ __global__ void __launch_bounds__(1024) kernel_res_ln(LnArgs g) {
         bet4[q] = *(const f32x4*)(g.beta + c0);
     }
 
-    // 40 one-KiB pieces per stage (8 row images each): wave w fetches pieces w, w + 16 and, the first eight waves, w + 32
-    const float* src[3];
+    // 40 one-KiB pieces per stage (8 row images each): 16 waves: wave w fetches pieces w, w + 16 and, the first eight, w + 32;
+    // 8 waves: w, w + 8, ..., w + 32
+    constexpr int MAXP = RB == 1 ? 3 : 5;
+    const float* src[MAXP];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int piece = wave + 16 * i;
+    for (int i = 0; i < MAXP; ++i) {
+        const int piece = wave + NWAVE * i;
         const int row = piece * 8 + (lane >> 3);
         const int slot = (lane & 7) ^ ((row >> 1) & 7);
         if (row < LN_BM) {
@@ -88,23 +93,27 @@ __global__ void __launch_bounds__(1024) kernel_res_ln(LnArgs g) {
     auto issue = [&](int kt) {
         float* const st = lds + (kt % NS) * LN_STAGE;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-            if (i < 2 || wave < 8)
+        for (int i = 0; i < MAXP; ++i)
+            if (RB == 2 || i < 2 || wave < 8)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + kt * 32),
-                                                 (__attribute__((address_space(3))) void*)(st + (wave + 16 * i) * 256), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(st + (wave + NWAVE * i) * 256), 16, 0, 0);
     };
 #pragma unroll
     for (int i = 0; i < NS - 1; ++i)
         if (i < nk) issue(i);
 
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-    f32x16 acc;
+    f32x16 acc[RB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
     for (int kt = 0; kt < nk; ++kt) {
-        // step kt has landed once at most the pieces of the NS - 2 following steps (3 or 2 each, by wave) are still in flight
+        // step kt has landed once at most the pieces of the NS - 2 following steps are still in flight
         if (kt + NS - 2 < nk) {
-            if (wave < 8)
+            if (RB == 2)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (NS - 2)) : "memory");
+            else if (wave < 8)
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (NS - 2)) : "memory");
             else
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NS - 2)) : "memory");
@@ -113,12 +122,13 @@ __global__ void __launch_bounds__(1024) kernel_res_ln(LnArgs g) {
         __builtin_amdgcn_s_barrier();
         if (kt + NS - 1 < nk) issue(kt + NS - 1);
         const float* st = lds + (kt % NS) * LN_STAGE;
-        f32x4 xv[4], wv[4];
-        {
-            const int row = 32 * rg + lr;
+        f32x4 xv[RB][4], wv[4];
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const int row = 32 * (rg0 + b) + lr;
             const float* rp = st + row * 32;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) xv[c] = *(const f32x4*)(rp + 4 * ((4 * lh + c) ^ ((row >> 1) & 7)));
+            for (int c = 0; c < 4; ++c) xv[b][c] = *(const f32x4*)(rp + 4 * ((4 * lh + c) ^ ((row >> 1) & 7)));
         }
         {
             const int row = LN_BM + 32 * cg + lr;
@@ -128,71 +138,90 @@ __global__ void __launch_bounds__(1024) kernel_res_ln(LnArgs g) {
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            const bf16x8 xh = __builtin_bit_cast(bf16x8, xv[2 * half]), xl = __builtin_bit_cast(bf16x8, xv[2 * half + 1]);
             const bf16x8 wh = __builtin_bit_cast(bf16x8, wv[2 * half]), wl = __builtin_bit_cast(bf16x8, wv[2 * half + 1]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc, 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < RB; ++b) {
+                const bf16x8 xh = __builtin_bit_cast(bf16x8, xv[b][2 * half]), xl = __builtin_bit_cast(bf16x8, xv[b][2 * half + 1]);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[b], 0, 0, 0);
+            }
         }
     }
-    // ---- epilogue: acc[4 q + e] = column 32 cg + 8 q + 4 lh + e of row 32 rg + lr ----
+    // ---- epilogue: acc[b][4 q + e] = column 32 cg + 8 q + 4 lh + e of row 32 (rg0 + b) + lr ----
     constexpr int PP = 65;                                      // pitch of a row of 64 four-column partials
     float* const P1 = lds;
     float* const P2 = lds + LN_BM * PP;
+    float* const TOT = lds + 2 * LN_BM * PP;                    // [64] row totals
     __syncthreads();                                            // the ring is dead
-    f32x4 v[4];
+    f32x4 v[RB][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int b = 0; b < RB; ++b) {
+        const int row = 32 * (rg0 + b) + lr;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[q][e] = res[q][e] + (acc[4 * q + e] + bias4[q][e]);
-        P1[(32 * rg + lr) * PP + 8 * cg + 2 * q + lh] = (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
-        if (row_ok) *(f32x4*)(g.X + (int64_t)row_m * LN_N + 32 * cg + 8 * q + 4 * lh) = v[q];
-    }
-    __syncthreads();
-    // the 64-lane butterfly sum of layernorm_kernel (partners 32, 16, 8, 4, 2, 1 apart): wave (rg, cg) sums rows 4 cg .. 4 cg + 3 of
-    // its row group, 16 lanes a row (lane j: partials j, j + 16, j + 32, j + 48, then the 8 / 4 / 2 / 1 exchanges), and leaves the
-    // totals in the LDS for everybody
-    float* const TOT = lds + 2 * LN_BM * PP;                  // [64] row totals
-    auto tree = [&](const float* Pm) {
-        const int trow = 32 * rg + 4 * cg + (lane >> 4), j = lane & 15;
-        const float* p = Pm + trow * PP;
-        float t = (p[j] + p[j + 32]) + (p[j + 16] + p[j + 48]);
-        t += __shfl_xor(t, 8, 64);
-        t += __shfl_xor(t, 4, 64);
-        t += __shfl_xor(t, 2, 64);
-        t += __shfl_xor(t, 1, 64);
-        if (j == 0) TOT[trow] = t;
-        __syncthreads();
-        const float r = TOT[32 * rg + lr];
-        __syncthreads();                                      // (TOT is written again by the second sum)
-        return r;
-    };
-    const float mean = tree(P1) * (1.0f / LN_N);
-    f32x4 d[4];
+        for (int q = 0; q < 4; ++q) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float ss = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            d[q][e] = v[q][e] - mean;
-            ss = fmaf(d[q][e], d[q][e], ss);
+            for (int e = 0; e < 4; ++e) v[b][q][e] = res[b][q][e] + (acc[b][4 * q + e] + bias4[q][e]);
+            P1[row * PP + 8 * cg + 2 * q + lh] = (v[b][q][0] + v[b][q][1]) + (v[b][q][2] + v[b][q][3]);
+            if (m0 + row < g.M) *(f32x4*)(g.X + (int64_t)(m0 + row) * LN_N + 32 * cg + 8 * q + 4 * lh) = v[b][q];
         }
-        P2[(32 * rg + lr) * PP + 8 * cg + 2 * q + lh] = ss;
     }
     __syncthreads();
-    const float rstd = 1.0f / sqrtf(tree(P2) * (1.0f / LN_N) + 1e-5f);
+    // the 64-lane butterfly sum of layernorm_kernel (partners 32, 16, 8, 4, 2, 1 apart): each wave sums four rows per pass, 16 lanes
+    // a row (lane j: partials j, j + 16, j + 32, j + 48, then the 8 / 4 / 2 / 1 exchanges), and leaves the totals in the LDS
+    auto tree = [&](const float* Pm, float (&out)[RB]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int c0 = 32 * cg + 8 * q + 4 * lh;
-        const f32x4 ga = gam4[q], be = bet4[q];
-        f32x4 o;
+        for (int b = 0; b < RB; ++b) {
+            const int trow = 32 * (rg0 + b) + 4 * cg + (lane >> 4), j = lane & 15;
+            const float* p = Pm + trow * PP;
+            float t = (p[j] + p[j + 32]) + (p[j + 16] + p[j + 48]);
+            t += __shfl_xor(t, 8, 64);
+            t += __shfl_xor(t, 4, 64);
+            t += __shfl_xor(t, 2, 64);
+            t += __shfl_xor(t, 1, 64);
+            if (j == 0) TOT[trow] = t;
+        }
+        __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = fmaf(d[q][e] * rstd, ga[e], be[e]);
-        if (g.y_split) {
-            const ddsp_u32x4 pk = ddsp_split4_pair(o, lh != 0, 32);      // (every lane takes part in the exchange)
-            if (row_ok) *(ddsp_u32x4*)(g.Y + (int64_t)row_m * LN_N + c0) = pk;
-        } else if (row_ok)
-            *(f32x4*)(g.Y + (int64_t)row_m * LN_N + c0) = o;
+        for (int b = 0; b < RB; ++b) out[b] = TOT[32 * (rg0 + b) + lr];
+        __syncthreads();                                      // (TOT is written again by the second sum)
+    };
+    float mean[RB], rstd[RB];
+    tree(P1, mean);
+    f32x4 d[RB][4];
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+        mean[b] *= (1.0f / LN_N);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                d[b][q][e] = v[b][q][e] - mean[b];
+                ss = fmaf(d[b][q][e], d[b][q][e], ss);
+            }
+            P2[(32 * (rg0 + b) + lr) * PP + 8 * cg + 2 * q + lh] = ss;
+        }
+    }
+    __syncthreads();
+    tree(P2, rstd);
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+        const int row_m = m0 + 32 * (rg0 + b) + lr;
+        const bool row_ok = row_m < g.M;
+        const float rs = 1.0f / sqrtf(rstd[b] * (1.0f / LN_N) + 1e-5f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c0 = 32 * cg + 8 * q + 4 * lh;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaf(d[b][q][e] * rs, gam4[q][e], bet4[q][e]);
+            if (g.y_split) {
+                const ddsp_u32x4 pk = ddsp_split4_pair(o, lh != 0, 32);      // (every lane takes part in the exchange)
+                if (row_ok) *(ddsp_u32x4*)(g.Y + (int64_t)row_m * LN_N + c0) = pk;
+            } else if (row_ok)
+                *(f32x4*)(g.Y + (int64_t)row_m * LN_N + c0) = o;
+        }
     }
 }
 
@@ -202,19 +231,28 @@ inline bool res_ln_ok(const LnArgs& g) {
              (uintptr_t)g.beta | (uintptr_t)g.Y) % 16) == 0;
 }
 
-inline hipError_t launch_res_ln(hipStream_t st, const LnArgs& g) {
+template <int RB>
+inline hipError_t launch_res_ln_rb(hipStream_t st, const LnArgs& g) {
     static std::atomic<uint64_t> done{0};   // devices on which the dynamic-LDS attribute has been set
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     const uint64_t bit = 1ull << (dev & 63);
     if (!(done.load(std::memory_order_acquire) & bit)) {
-        e = hipFuncSetAttribute((const void*)kernel_res_ln<LN_NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LN_LDS_BYTES);
+        e = hipFuncSetAttribute((const void*)kernel_res_ln<LN_NS, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LN_LDS_BYTES);
         if (e != hipSuccess) return e;
         done.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL(kernel_res_ln<LN_NS>, dim3((unsigned)((g.M + LN_BM - 1) / LN_BM)), dim3(1024), LN_LDS_BYTES, st, g);
+    hipLaunchKernelGGL((kernel_res_ln<LN_NS, RB>), dim3((unsigned)((g.M + LN_BM - 1) / LN_BM)), dim3(1024 / RB), LN_LDS_BYTES, st, g);
     return hipSuccess;
+}
+inline hipError_t launch_res_ln(hipStream_t st, const LnArgs& g) {
+    static int rb = -1;     // DDSP_GEMM_LN_RB=1: sixteen waves of one 32 x 32 block each (measurement aid)
+    if (rb < 0) {
+        const char* e = getenv("DDSP_GEMM_LN_RB");
+        rb = (e && e[0] == '1') ? 1 : 2;
+    }
+    return rb == 1 ? launch_res_ln_rb<1>(st, g) : launch_res_ln_rb<2>(st, g);
 }
 
 }  // namespace gemm
