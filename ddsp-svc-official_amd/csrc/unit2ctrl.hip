@@ -1678,6 +1678,11 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         const char* e = getenv("DDSP_GEMM_LN");
         gemm_ln_on = (e && e[0] == '0') ? 0 : 1;
     }
+    static int64_t gemm_ln_min = -1;   // DDSP_GEMM_LN_MIN: rows from which the fused kernel runs (measurement aid)
+    if (gemm_ln_min < 0) {
+        const char* e = getenv("DDSP_GEMM_LN_MIN");
+        gemm_ln_min = e ? atoll(e) : 2048;
+    }
     bool ln_done = false;   // the next LayerNorm's output has been written by the producer of its input
     auto ln_args = [&](const gemm::Args& g, const float* x_res, float* x_dst, const float* bias, const float* gamma,
                        const float* beta, float* y_out) {
@@ -1685,7 +1690,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
     };
     auto ln_fusable = [&](const gemm::Args& g, const gemm::LnArgs& a) {
         return gemm_ln_on && !ksplit && !bf.l[0].pre && g.math == DDSP_MATH_SPLIT_BF16 && g.B_split && g.A_split && asplit &&
-               g.N == D && M >= 2048 && gemm::res_ln_ok(a);
+               g.N == D && M >= gemm_ln_min && gemm::res_ln_ok(a);
     };
     {   // weight preparation, one launch (u2c_prepare_kernel)
         PrepArgs pa;
