@@ -30,3 +30,11 @@ for _ in range(N):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / N * 1e3
 print(f"frames {L} ({L * 512 / 44100:.2f} s of audio): {ms:.3f} ms per call = {L * 512 / 44.1 / ms:.0f}x real time")
+# sustained: the same call for ~1 s (the clocks of the pool's boxes settle lower under a sustained matrix load)
+N = 250
+t0 = time.perf_counter()
+for _ in range(N):
+    out = gen(mel, f0, rand_ini=rand_ini[0])
+torch.cuda.synchronize()
+ms2 = (time.perf_counter() - t0) / N * 1e3
+print(f"sustained ({N} calls back to back): {ms2:.3f} ms per call = {L * 512 / 44.1 / ms2:.0f}x real time")

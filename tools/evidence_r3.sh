@@ -25,12 +25,15 @@ stats sins256_b64 python3 bench.py --model Sins256 --steps 20 --warmup 5 --no-cp
 stats train_b32 python3 bench.py --mode train --steps 10 --warmup 3
 stats realtime python3 bench.py --mode realtime --steps 50 --warmup 10
 stats enhancer_860 python3 tools/enhancer_time.py 860
+stats causal_b64 python3 tools/causal_time.py 64
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 python3 bench.py --mode train --steps 20 --warmup 5 > $OUT/bench_train.json 2>> $OUT/bench.err
 python3 bench.py --mode train --model Sins256 --steps 20 --warmup 5 > $OUT/bench_train_sins256.json 2>> $OUT/bench.err
 python3 bench.py --mode realtime --steps 200 --warmup 20 > $OUT/bench_realtime.json 2>> $OUT/bench.err
 python3 tools/secondary_bench.py > $OUT/secondary_configs.json 2>> $OUT/bench.err || true
 python3 tools/enhancer_time.py 860 > $OUT/enhancer_time.txt 2>> $OUT/bench.err || true
+python3 tools/causal_time.py 64 > $OUT/causal_time.txt 2>> $OUT/bench.err || true
+python3 tools/phase_scan_time.py > $OUT/phase_scan_time.txt 2>> $OUT/bench.err || true
 rm -rf $OUT/pmc_fetch/*/*.db $OUT/pmc_write/*/*.db $OUT/pmc_sq/*/*.db 2>/dev/null || true
 find $OUT -name "*.db" -delete
 du -sh $OUT

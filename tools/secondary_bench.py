@@ -107,7 +107,7 @@ mc = CombSub(44100, 512, cfg["n_mag_allpass"], cfg["n_mag_harmonic"], cfg["n_mag
 mc.load_state_dict(model64.state_dict(), strict=True)
 mc = mc.to(dev).eval()
 with torch.no_grad():
-    t = timeit(lambda: mc(inp64["units"], inp64["f0"], inp64["volume"], inp64["spk_id"], noise_seed=1), n=5, warm=2)
+    t = timeit(lambda: mc(inp64["units"], inp64["f0"], inp64["volume"], inp64["spk_id"], noise_seed=1), n=20, warm=3)
 out["CombSub_causal_forward_B64"] = {"ms": t * 1e3, "samples_per_s": B * Fr * 512 / t, "x_realtime": B * Fr * 512 / t / 44100}
 # (the model constructors print a banner line each; the JSON goes to its own file when a path is given)
 if len(sys.argv) > 1:
