@@ -68,6 +68,9 @@ struct Args {
     // x, x + 8, ... with ALL their column tiles, so the A rows of a row block are fetched into one L2 instead of eight
     // (the leftover tiles_m % 8 row blocks are dealt round-robin as before).
     int xcd;
+    // ... and the launch covers all tiles but the last xcd_cut of the linear order (a multiple of 8, at most the leftover
+    // region: every XCD's queue is one tile shorter per 8), which a second launch runs as quadrant tiles (sub_from)
+    int xcd_cut;
     // DMA kernel: batch index z also starts its k range kz floats into A's and B's rows (the taps of an implicit-im2col
     // convolution follow from the shifted k): a K-split whose partial products the caller's epilogue stores per z
     int kz;
@@ -393,9 +396,9 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? 3 : BM * BN <= 128 * 128 ?
     // Persistent workgroup: walks output tiles blockIdx.x, +gridDim.x, ... and treats their k-tiles as ONE stream
     // (step = tile_i*nk + kt), so the DMA of the next tile's first k-tiles is already in flight while the current
     // tile's last MFMAs and its epilogue stores run: no per-tile prologue latency.
-    const bool xcd_order = g.xcd && (gridDim.x & 7) == 0 && g.sub_from == 0 && total_tiles == tiles_m * tiles_n;
+    const bool xcd_order = g.xcd && (gridDim.x & 7) == 0 && g.sub_from == 0 && total_tiles == tiles_m * tiles_n - g.xcd_cut;
     const int xq0 = (int)blockIdx.x >> 3, xgs = (int)gridDim.x >> 3, xx = (int)blockIdx.x & 7;
-    const int xown = (tiles_m / 8) * tiles_n, xleft = (tiles_m % 8) * tiles_n;
+    const int xown = (tiles_m / 8) * tiles_n, xleft = (tiles_m % 8) * tiles_n - g.xcd_cut;
     int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     if (xcd_order) {
         const int qx = xown + (xleft > xx ? (xleft - xx + 7) / 8 : 0);
@@ -752,7 +755,7 @@ inline int xcd_default(int math) {
 template <int BM, int BN, class Epi, int NS = 3, int NW = 8, int A_MODE = A_PLAIN>
 inline void dma_go(hipStream_t st, const Args& g0, int batch, const Epi& epi, int total_override = -1) {
     Args g = g0;
-    if (g.xcd < 0) g.xcd = (batch == 1 && total_override < 0) ? xcd_default(g.math) : 0;
+    if (g.xcd < 0) g.xcd = (batch == 1 && (total_override < 0 || g.xcd_cut > 0)) ? xcd_default(g.math) : 0;
     if (g.math == 3 && g.B_split && g.A_split) {
         Args h = g;
         h.B = g.B_split;
@@ -793,6 +796,18 @@ inline int64_t t128_min() {
 //                                       64x64 / 4 waves for small or skinny problems.
 // Larger tiles raise FLOP per staged byte (the L2->LDS operand stream, ~4-6 TB/s chip-wide, is what caps these
 // K=256..768 shapes near 85 TFLOP/s) but leave CUs idle at 11008 = 2*43*128 rows; see DESIGN.md section 9.
+// DDSP_GEMM_TAIL_CUT=1 (measurement aid, off): with the XCD-aware order too, the few tiles of a last, nearly empty round are cut
+// out of the launch and run as quadrant tiles in a second one.  Measured at the bench shape (QKV: 1032 = 2 x 512 + 8 tiles):
+// Linear family 0.361 -> 0.372 ms - the eight tail tiles run alone on their CUs and take about what the second launch costs.
+inline bool tail_cut() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("DDSP_GEMM_TAIL_CUT");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+
 template <bool A_KC, bool B_KC, int A_MODE, class Epi>
 inline void launch(hipStream_t st, const Args& g, int batch, const Epi& epi) {
     auto blocks = [&](int bm, int bn) {
@@ -848,10 +863,17 @@ inline void launch(hipStream_t st, const Args& g, int batch, const Epi& epi) {
                 const int rem = total % 512;
                 bool split = false;
                 if constexpr (!epi_is_gated<Epi>::value) {
-                    if (batch == 1 && rem > 0 && rem <= 64 && !(g.xcd > 0 || (g.xcd < 0 && xcd_default(g.math)))) {
+                    const bool xcd_on = g.xcd > 0 || (g.xcd < 0 && xcd_default(g.math));
+                    // (XCD order: the cut tiles must come off every XCD's queue evenly and out of the leftover row blocks)
+                    const int tm = (g.M + 127) / 128, tn = (g.N + 127) / 128;
+                    const bool cut_ok = !xcd_on || (tail_cut() && rem % 8 == 0 && rem <= (tm % 8) * tn);
+                    if (batch == 1 && rem > 0 && rem <= 64 && cut_ok) {
                         split = true;
-                        dma_go<128, 128, Epi, 2>(st, g, batch, epi, total - rem);
+                        Args m = g;
+                        if (xcd_on) m.xcd_cut = rem;
+                        dma_go<128, 128, Epi, 2>(st, m, batch, epi, total - rem);
                         Args r = g;
+                        r.xcd = 0;
                         r.sub_from = total - rem;
                         r.parent_tn = (g.N + 127) / 128;
                         dma_go<64, 64, Epi, 3, 4>(st, r, 1, epi, 4 * rem);
@@ -905,6 +927,7 @@ inline Args make(const float* A, int64_t lda, const float* B, int64_t ldb, int M
     g.math = 0;
     g.B_split = nullptr;
     g.A_split = 0;
+    g.xcd_cut = 0;
     g.xcd = -1;   // decided by dma_go from the product arithmetic (see there)
     g.kz = 0;
     return g;
