@@ -72,9 +72,14 @@ __device__ __forceinline__ float group_max(float x) {
     return x;
 }
 
+// PART: the item's frame tiles are dealt over the four waves of a workgroup (tile ft to wave ft & 3) and the partial sums meet
+// in the LDS - for few (utterance, head) pairs, where one wave per item walks all tiles alone and the chip is mostly empty
+template <bool PART>
 __device__ __forceinline__ void performer_kv_item(const float* __restrict__ k, const float* __restrict__ v,
                                                   const float* __restrict__ P, int Fr, float* __restrict__ ctxT,
-                                                  float* __restrict__ ks, int bh, int jt) {
+                                                  float* __restrict__ ks, int bh, int jt, int ft_first = 0,
+                                                  float* __restrict__ part = nullptr) {
+    constexpr int FSTEP = PART ? 4 : 1;
     const int b = bh / H, h = bh % H;
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const int j = 16 * jt + c;                  // this lane's feature (column of S, row of ctx)
@@ -112,7 +117,7 @@ __device__ __forceinline__ void performer_kv_item(const float* __restrict__ k, c
             vv[t] = *(const f32x4_t*)(vb + f * INNER + 4 * c);
         }
         // next tile's k rows (used only in the next call)
-        int nf = 16 * (ft + 1) + c;
+        int nf = 16 * (ft + FSTEP) + c;
         nf = nf < Fr ? nf : last;
         load_quarter_row(kb + nf * INNER + 16 * g, nxt);
         // all eight loads of the tile are issued HERE, a whole product ahead of their first use
@@ -141,11 +146,33 @@ __device__ __forceinline__ void performer_kv_item(const float* __restrict__ k, c
                 acc[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t], vv[t][et], acc[et], 0, 0, 0);
     };
     float ka[16], kc[16];
-    load_quarter_row(kb + (c < Fr ? c : last) * INNER + 16 * g, ka);
+    {
+        const int f0 = 16 * ft_first + c;
+        load_quarter_row(kb + (f0 < Fr ? f0 : last) * INNER + 16 * g, ka);
+    }
 #pragma unroll 1
-    for (int ft = 0; ft < n_ft; ft += 2) {
+    for (int ft = ft_first; ft < n_ft; ft += 2 * FSTEP) {
         tile(ft, ka, kc);
-        if (ft + 1 < n_ft) tile(ft + 1, kc, ka);
+        if (ft + FSTEP < n_ft) tile(ft + FSTEP, kc, ka);
+    }
+    if constexpr (PART) {
+        // waves 1..3 hand their partial sums to wave 0 (added in wave order: the result does not depend on timing)
+        const int wave = threadIdx.x >> 6;
+        if (wave > 0) {
+            f32x4_t* dst = (f32x4_t*)part + ((wave - 1) * 5) * 64 + lane;
+#pragma unroll
+            for (int et = 0; et < 4; ++et) dst[et * 64] = acc[et];
+            dst[4 * 64] = ksum4;
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const f32x4_t* src = (const f32x4_t*)part + (w * 5) * 64 + lane;
+#pragma unroll
+            for (int et = 0; et < 4; ++et) acc[et] += src[et * 64];
+            ksum4 += src[4 * 64];
+        }
     }
     float* kr = ks + (int64_t)bh * KST;
     const float ksum = group_sum((ksum4[0] + ksum4[1]) + (ksum4[2] + ksum4[3]));
@@ -175,7 +202,18 @@ __global__ void __launch_bounds__(256, 4) performer_kv_kernel(const float* __res
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int jt = 4 * grp + wave;
     if (jt >= NJT) return;
-    performer_kv_item(k, v, P, Fr, ctxT, ks, bh, jt);
+    performer_kv_item<false>(k, v, P, Fr, ctxT, ks, bh, jt);
+}
+
+// one (utterance, head, feature tile) per workgroup, its frame tiles over the four waves (few work items: see PART above)
+__global__ void __launch_bounds__(256, 4) performer_kv_split_kernel(const float* __restrict__ k, const float* __restrict__ v,
+                                                                    const float* __restrict__ P, int Fr,
+                                                                    float* __restrict__ ctxT, float* __restrict__ ks) {
+    __shared__ float part[3 * 5 * 64 * 4];
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int jt = slot % NJT, bh = (slot / NJT) * 8 + xcd;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    performer_kv_item<true>(k, v, P, Fr, ctxT, ks, bh, jt, wave, part);
 }
 
 // Measurement variant (DDSP_ATTN_PERSIST=1, tools/attn_dispatch.py): as many waves as the chip holds at once, each
@@ -197,7 +235,7 @@ __global__ void __launch_bounds__(256, 4) performer_kv_persist_kernel(const floa
         const int slot = s_item;
         if (slot >= n_items) return;
         const int grp = slot % KV_GROUPS, bh = (slot / KV_GROUPS) * 8 + xcd, jt = 4 * grp + wave;
-        if (jt < NJT) performer_kv_item(k, v, P, Fr, ctxT, ks, bh, jt);
+        if (jt < NJT) performer_kv_item<false>(k, v, P, Fr, ctxT, ks, bh, jt);
     }
 }
 
@@ -631,6 +669,15 @@ void performer_kv(hipStream_t st, const float* k, const float* v, const float* P
     if (int* ctr = persist_counter()) {
         (void)hipMemsetAsync(ctr, 0, 32, st);
         hipLaunchKernelGGL(performer_kv_persist_kernel, dim3(1024), dim3(256), 0, st, k, v, P, Fr, ctxT, ks, ctr, KV_GROUPS * B);
+        return;
+    }
+    static int kv_split_max = -1;   // DDSP_ATTN_KVSPLIT_MAX: (utterance, head) pairs up to which the frame tiles of an item are dealt over four waves
+    if (kv_split_max < 0) {
+        const char* e = getenv("DDSP_ATTN_KVSPLIT_MAX");
+        kv_split_max = e ? atoi(e) : 128;
+    }
+    if (B * H <= kv_split_max) {
+        hipLaunchKernelGGL(performer_kv_split_kernel, dim3((unsigned)(NJT * B * H)), dim3(256), 0, st, k, v, P, Fr, ctxT, ks);
         return;
     }
     // B*H is a multiple of 8, so the XCD-aware decode of the 1-D grid covers every (head, tile group) exactly once
