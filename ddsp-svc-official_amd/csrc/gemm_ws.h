@@ -110,7 +110,10 @@ constexpr int WS_PRODUCT_WAVES = 8, WS_LOADER_WAVES = 4, WS_THREADS = 64 * (WS_P
 // VEC: the epilogue's rows are 16-byte aligned and N % BN == 0 (checked by the launcher); else dword stores per element.
 // ABLATE (timing experiments only): 1 no matrix instructions, 2 no DMA, 4 no epilogue stores, 8 product waves only join the
 // barriers, 16 no lgkmcnt(0) before the barrier (WRONG results), 32 no epilogue pieces at all, 64 loaders issue every other piece.
-template <int BM, int BN, class Epi, int NS, int MATH, bool VEC, int ABLATE = 0>
+// A_MODE: A_PLAIN, or A_CONVK (implicit im2col of a "same" convolution with Args::ktaps taps and dilation Args::dil, k = tap *
+// Cin + c, Cin % 32 == 0: the loader waves move an A row's source by the tap's frame offset, or to the zero page when that frame
+// lies outside the utterance - as kernel_dma does).
+template <int BM, int BN, class Epi, int NS, int MATH, bool VEC, int ABLATE = 0, int A_MODE = A_PLAIN>
 __global__ void __launch_bounds__(WS_THREADS) kernel_ws(Args g, Epi epi, int tiles_m, int tiles_n, int total_tiles) {
     constexpr int TM = BM / 128, TN = BN / 64;            // 32x32 accumulator tiles per product wave (4 x 2 wave grid)
     static_assert(BM % 128 == 0 && BN % 64 == 0 && TM >= 1 && TN >= 1, "tile must split over the 4 x 2 product waves");
@@ -160,6 +163,8 @@ __global__ void __launch_bounds__(WS_THREADS) kernel_ws(Args g, Epi epi, int til
         // ================================ loader waves ================================
         const int lw = wave - WS_PRODUCT_WAVES;
         const float* src[PPL];
+        constexpr int PA = BM / 8 / WS_LOADER_WAVES;   // this wave's pieces i < PA are A rows
+        int conv_f[PA];                                // A_CONVK: frame (inside its utterance) of each A row this lane fetches
         auto tile_src = [&](int tile) {
             const int z = tile / per_z, rem = tile - z * per_z;
             const int m0 = (rem / tiles_n) * BM, n0 = (rem % tiles_n) * BN;
@@ -174,6 +179,7 @@ __global__ void __launch_bounds__(WS_THREADS) kernel_ws(Args g, Epi epi, int til
                     int m = m0 + row;
                     m = m < g.M ? m : g.M - 1;     // rows past the edge re-read the last row (never stored)
                     src[i] = A + (int64_t)m * g.lda + slot * 4;
+                    if constexpr (A_MODE == A_CONVK) conv_f[i < PA ? i : 0] = m % g.Fr;
                 } else {
                     int n = n0 + row - BM;
                     n = n < g.N ? n : g.N - 1;
@@ -198,10 +204,23 @@ __global__ void __launch_bounds__(WS_THREADS) kernel_ws(Args g, Epi epi, int til
                                                  16, 0, 0);
             }
             if (!(ABLATE & 2)) {
+                int koff = ikt * 32, conv_off = 0;
+                if constexpr (A_MODE == A_CONVK) {
+                    const int tap = koff / g.Cin;
+                    koff -= tap * g.Cin;
+                    conv_off = (tap - (g.ktaps - 1) / 2) * g.dil;
+                }
 #pragma unroll
                 for (int i = 0; i < PPL; i += ((ABLATE & 64) ? 2 : 1)) {
                     const int piece = lw + WS_LOADER_WAVES * i;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + ikt * 32),
+                    const float* p = src[i] + ikt * 32;
+                    if constexpr (A_MODE == A_CONVK) {
+                        if (i < PA) {
+                            const int f = conv_f[i < PA ? i : 0] + conv_off;
+                            p = (f >= 0 && f < g.Fr) ? src[i] + (int64_t)conv_off * g.lda + koff : g.zeros + (lane & 7) * 4;
+                        }
+                    }
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                                      (__attribute__((address_space(3))) void*)(lds + istage * STAGE + piece * 256),
                                                      16, 0, 0);
                 }
@@ -505,12 +524,12 @@ __global__ void __launch_bounds__(WS_THREADS) kernel_ws(Args g, Epi epi, int til
     }
 }
 
-template <int BM, int BN, class Epi, int NS, int MATH, bool VEC, int ABLATE = 0>
+template <int BM, int BN, class Epi, int NS, int MATH, bool VEC, int ABLATE = 0, int A_MODE = A_PLAIN>
 inline hipError_t launch_ws_one(hipStream_t st, const Args& g, const Epi& epi) {
     constexpr size_t lds_bytes = (size_t)NS * (BM + BN) * 128 + 2048 + (Epi::kExtra ? (size_t)BM * BN * 4 : 0);   // ring + bias + residual tile
     static_assert(lds_bytes <= 160 * 1024, "ring does not fit the LDS");
     static_assert(lds_bytes > 80 * 1024, "one workgroup per CU is assumed");
-    auto kfn = kernel_ws<BM, BN, Epi, NS, MATH, VEC, ABLATE>;
+    auto kfn = kernel_ws<BM, BN, Epi, NS, MATH, VEC, ABLATE, A_MODE>;
     static std::atomic<uint64_t> done{0};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -544,6 +563,18 @@ inline hipError_t ws_go(hipStream_t st, const Args& g0, const Epi& epi) {
     if (!(g.math == 3 && g.B_split && epi.vec_ok() && g.N % BN == 0)) return hipErrorInvalidValue;
     g.B = g.B_split;
     return g.A_split ? launch_ws_one<BM, BN, Epi, NS, 8, true>(st, g, epi) : launch_ws_one<BM, BN, Epi, NS, 7, true>(st, g, epi);
+}
+
+// the same for a "same" convolution as an implicit-im2col product (A_CONVK: Args::Fr / Cin / ktaps / dil / zeros set by the caller,
+// Cin % 32 == 0); pre-split weights, activations pre-split (mode 8) or fp32 (mode 7)
+template <int BM, int BN, class Epi, int NS>
+inline hipError_t ws_conv_go(hipStream_t st, const Args& g0, const Epi& epi) {
+    Args g = g0;
+    if (g.xcd < 0) g.xcd = 1;
+    if (!(g.math == 3 && g.B_split && g.zeros && g.Cin % 32 == 0 && epi.vec_ok() && g.N % BN == 0)) return hipErrorInvalidValue;
+    g.B = g.B_split;
+    return g.A_split ? launch_ws_one<BM, BN, Epi, NS, 8, true, 0, A_CONVK>(st, g, epi)
+                     : launch_ws_one<BM, BN, Epi, NS, 7, true, 0, A_CONVK>(st, g, epi);
 }
 
 }  // namespace gemm

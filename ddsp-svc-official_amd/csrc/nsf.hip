@@ -15,6 +15,7 @@
 // These kernels are correct-first: fp32 MFMA on the register-staged GEMM kernel, no tuning (the enhancer is the step after
 // the hot path, not part of the benchmarked one).
 #include "gemm_f32.h"
+#include "gemm_ws.h"
 
 #include <stdlib.h>
 
@@ -860,6 +861,45 @@ struct EpiAddBias {   // y = acc + bias[n] (+ res): C = y and / or Cact = leaky_
     }
 };
 
+// EpiAddBias for the wave-specialised kernel (gemm_ws.h): bias through the loaders' LDS copy, the residual tile (RES) too
+template <bool RES>
+struct WsConv {
+    float* C;
+    float* Cact;
+    const float* res;
+    int64_t ldc;
+    const float* bias;
+    float slope;
+    int act_split;
+    static constexpr bool kExtra = RES, kGated = false;
+    __device__ __forceinline__ f32x4 bias4(int n) const { return bias ? *(const gemm::f32x4_u*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ float bias1(int n) const { return bias ? bias[n] : 0.f; }
+    __device__ __forceinline__ const float* extra_ptr() const { return res; }
+    __device__ __forceinline__ void emit4(int, int m, int n, f32x4 v, f32x4 e) const {
+        const int64_t o = (int64_t)m * ldc + n;
+        if constexpr (RES) v = v + e;
+        if (C) *(f32x4*)(C + o) = v;
+        if (Cact) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
+            if (act_split)   // the lane 4 further on holds the other half of this group of 8 columns (same row)
+                *(ddsp_u32x4*)(Cact + o) = ddsp_split4_pair(v, (n & 4) != 0, 4);
+            else
+                *(f32x4*)(Cact + o) = v;
+        }
+    }
+    __device__ __forceinline__ void emit1(int, int m, int n, float v) const {   // (edge path: never taken, the launcher asks for whole tiles)
+        const int64_t o = (int64_t)m * ldc + n;
+        if (RES) v += res[o];
+        if (C) C[o] = v;
+        if (Cact && !act_split) Cact[o] = v > 0.f ? v : v * slope;
+    }
+    __host__ __device__ const float* bias_ptr() const { return bias; }
+    __host__ bool vec_ok() const {
+        return (((uintptr_t)C | (uintptr_t)Cact | (uintptr_t)res | (uintptr_t)bias) % 16) == 0 && ldc % 4 == 0;
+    }
+};
+
 }  // namespace
 
 // ---- the same for the 32-channel stage: v_mfma_f32_32x32x16_bf16, two k-steps per tap, row images as in conv_small32_bf16_kernel ----
@@ -1171,6 +1211,43 @@ extern "C" int ddsp_conv1d(ddsp_ctx* ctx, void* stream, const float* x, const fl
             g.B_split = w_split;
             g.A_split = x_split ? 1 : 0;
             if (x_split) g.B = w_split;   // (mode 8 reads only the split copies)
+        }
+        // Long products with pre-split weights at sizes that fill the chip CAN run on the wave-specialised kernel (gemm_ws.h) with
+        // per-tap row pointers - 128x128 tiles without a residual, 128x64 with one (its tile travels through the LDS too).
+        // Measured at 860 frames (rocprofv3, per launch): 128x128 without residual 53.4 -> 48.7 us; 128x64 without residual 45.2 ->
+        // 44.9; with the residual tile (128x64 also for the 128-channel stage, whose rows are then staged twice) 63 us against
+        // 45 - 53 on kernel_dma; the generator as a whole 3.66 ms with either choice (3.69 with the 128x128 form, 3.64 with all).
+        // OFF by default: DDSP_CONV_WS bit 1 = the 128x128 form, bit 2 = the 128x64 forms as well (measurement aid).
+        static int conv_ws = -1;
+        if (conv_ws < 0) {
+            const char* ev = getenv("DDSP_CONV_WS");
+            conv_ws = ev ? atoi(ev) : 0;
+        }
+        if (conv_ws && g.math == DDSP_MATH_SPLIT_BF16 && g.B_split && Cout % 64 == 0 && gemm::ws_ok(g, 5, residual != nullptr)) {
+            hipError_t he = hipErrorInvalidValue;
+            bool ran = false;
+            if (residual) {
+                WsConv<true> ew{out, out_act, residual, Cout, bias, act_slope, act_split ? 1 : 0};
+                if ((conv_ws & 2) && ew.vec_ok() && blocks(128, 64) >= 256) {
+                    he = gemm::ws_conv_go<128, 64, WsConv<true>, 5>(st, g, ew);
+                    ran = true;
+                }
+            } else {
+                WsConv<false> ew{out, out_act, nullptr, Cout, bias, act_slope, act_split ? 1 : 0};
+                if (ew.vec_ok() && Cout % 128 == 0 && blocks(128, 128) >= 256) {
+                    he = gemm::ws_conv_go<128, 128, WsConv<false>, 4>(st, g, ew);
+                    ran = true;
+                } else if ((conv_ws & 2) && ew.vec_ok() && blocks(128, 64) >= 256) {
+                    he = gemm::ws_conv_go<128, 64, WsConv<false>, 5>(st, g, ew);
+                    ran = true;
+                }
+            }
+            if (ran) {
+                DDSP_HIP(ctx, he);
+                ddsp_prof_end(ctx, st, 2.0 * T * (double)Cout * ktaps * Cin, 4.0 * T * ((double)Cin + Cout));
+                DDSP_LAUNCH_CHECK(ctx);
+                return DDSP_OK;
+            }
         }
         static int conv_tile = -1;
         if (conv_tile < 0) {
