@@ -1824,7 +1824,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         return (ws_mask & layer_bit) && presplit_w && g.math == DDSP_MATH_SPLIT_BF16 && gemm::ws_ok(g) && g.N % 128 == 0 &&
                (int64_t)((g.M + 127) / 128) * (g.N / 128) >= 512;
     };
-    static int dw_pair = -1;   // DDSP_DW_PAIR=0: the one-channel depthwise kernel at every size (measurement aid)
+    static int dw_pair = -1;   // DDSP_DW_PAIR (measurement aid): 0 the one-channel depthwise kernel at every size, 1 / 2 the register pair kernel (runs of 16 / 14 frames), 3 (default) the LDS-tiled kernel
     if (dw_pair < 0) {
         const char* e = getenv("DDSP_DW_PAIR");
         dw_pair = e ? atoi(e) : 3;
