@@ -107,6 +107,7 @@ SIGNATURES = {
     "ddsp_gemm_f32": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _i64, _int, _vp, _vp, _i64, _int, _int, _int, _int, _int]),
     "ddsp_performer_attention": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _int]),
     "ddsp_profile_begin": (_int, [_vp, _u64]),
+    "ddsp_profile_mask": (_int, [_vp, _u64]),
     "ddsp_profile_end": (_int, [_vp, _c.POINTER(ProfEntry), _int, _c.POINTER(_int)]),
     "ddsp_unit2ctrl_fwd": (_int, [_vp, _vp, _c.POINTER(U2CWeights), _vp, _vp, _vp, _vp, _vp, _i64,
                                   _c.POINTER(_i64), _c.POINTER(_f32), _int, _i64, _i64, _vp]),
@@ -240,6 +241,13 @@ class Context:
         for f in (families if families is not None else FAMILIES):
             mask |= 1 << FAMILIES.index(f)
         self._check(self.lib.ddsp_profile_begin(self.handle, mask), "ddsp_profile_begin")
+
+    def profile_mask(self, families):
+        """While armed: bracket only `families` from now on ([] pauses); the records taken so far are kept."""
+        mask = 0
+        for f in families:
+            mask |= 1 << FAMILIES.index(f)
+        self._check(self.lib.ddsp_profile_mask(self.handle, mask), "ddsp_profile_mask")
 
     def profile_end(self):
         """-> {family: {launches, ms_total, flops_total, bytes_total}} (waits for the recorded events)."""

@@ -380,6 +380,9 @@ typedef struct ddsp_prof_entry {
     double bytes_total;
 } ddsp_prof_entry;
 int ddsp_profile_begin(ddsp_ctx* ctx, uint64_t family_mask);
+/* While armed: change the bracketed families (0 = pause) without dropping the records taken so far - for callers that bracket a
+ * SAMPLE of their steps (bench.py: every fifth step of the timed region), since an event record costs ~2 us of stream time. */
+int ddsp_profile_mask(ddsp_ctx* ctx, uint64_t family_mask);
 int ddsp_profile_end(ddsp_ctx* ctx, ddsp_prof_entry* out, int max_entries, int* n_entries);
 
 #ifdef __cplusplus
