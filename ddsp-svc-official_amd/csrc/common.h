@@ -47,6 +47,11 @@ struct ddsp_ctx {
     char* scratch;
     size_t scratch_bytes;
     size_t scratch_used;
+    // prepared weights of the control network (ddsp_u2c_weights::version != 0): one slot
+    char* wcache;
+    size_t wcache_bytes;
+    uint64_t wcache_key, wcache_version;   // hash of the caller's struct (pointers, sizes) / its change counter; key 0 = empty
+    int wcache_flags;                      // what the slot holds: bit 0 split copies, bit 1 fused-GLU order, bit 2 attention pieces
     ddsp_table tables[64];
     int n_tables;
     uint64_t table_clock;

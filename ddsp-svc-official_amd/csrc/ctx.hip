@@ -3,7 +3,7 @@
 
 #include <stdlib.h>
 
-#define DDSP_ABI_VERSION 4   // 2: ddsp_rss_loss takes the hops; 3: ddsp_conv1d / ddsp_nsf_mean emit activated (split) copies, kept-activation entry points; 4: ddsp_retime_f0
+#define DDSP_ABI_VERSION 5   // 2: ddsp_rss_loss takes the hops; 3: ddsp_conv1d / ddsp_nsf_mean emit activated (split) copies, kept-activation entry points; 4: ddsp_retime_f0; 5: ddsp_u2c_weights::version (prepared-weight cache)
 
 extern "C" int ddsp_abi_version(void) { return DDSP_ABI_VERSION; }
 
@@ -35,6 +35,7 @@ extern "C" int ddsp_ctx_destroy(ddsp_ctx* ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->packed) (void)hipFree(ctx->packed);
     if (ctx->zero_page) (void)hipFree(ctx->zero_page);
+    if (ctx->wcache) (void)hipFree(ctx->wcache);
     if (ctx->dev_error_host) (void)hipHostFree(ctx->dev_error_host);
     if (ctx->prof) {
         for (int i = 0; i < ctx->prof_events_made; ++i) {

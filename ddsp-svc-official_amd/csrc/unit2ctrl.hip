@@ -1576,6 +1576,9 @@ struct LayerBufs {
 struct U2CBufs {
     float *w1, *w2, *wh, *wqkv, *bqkv, *wglu, *bglu, *wdw, *wout, *wpw2, *p3, *t1, *t2, *gst, *y_final, *kpart;
     LayerBufs l[3];
+    // the weight buffers live in the context's prepared-weight slot: what it holds (bit 0 prepared, bit 1 with split copies, bit 2
+    // in fused-GLU order, bit 3 attention pieces), updated by the forward that prepares; null: prepare on every call
+    int* wstate = nullptr;
 };
 
 struct Arena {  // sizes first (dry run), then pointers
@@ -1607,8 +1610,8 @@ struct Arena {  // sizes first (dry run), then pointers
     }
 };
 
-static void plan_forward(Arena& a, U2CBufs& bf, const ddsp_u2c_weights& w, int64_t B, int64_t Fr, bool keep) {
-    const size_t M = (size_t)(B * Fr), M8 = M * H;
+// the prepared weights (u2c_prepare_kernel, performer_p3): from the arena, or (cached != null) from the context's slot
+static void plan_weights(Arena& a, U2CBufs& bf, const ddsp_u2c_weights& w) {
     bf.w1 = a.get((size_t)D * 3 * w.n_unit);
     bf.w2 = a.get((size_t)D * 3 * D);
     bf.wh = a.get((size_t)w.n_out * D);
@@ -1620,6 +1623,11 @@ static void plan_forward(Arena& a, U2CBufs& bf, const ddsp_u2c_weights& w, int64
     bf.wout = a.get((size_t)3 * D * INNER);          // out-projection / pw2 weights as bf16 hi/lo groups (split GEMMs)
     bf.wpw2 = a.get((size_t)3 * D * INNER);
     bf.p3 = a.get((size_t)3 * PERFORMER_P3_BYTES / 4);  // projection matrices as bf16 pieces (split-bf16 attention)
+}
+
+static void plan_forward(Arena& a, U2CBufs& bf, const ddsp_u2c_weights& w, int64_t B, int64_t Fr, bool keep, bool weights_cached = false) {
+    const size_t M = (size_t)(B * Fr), M8 = M * H;
+    if (!weights_cached) plan_weights(a, bf, w);
     bf.t1 = a.get(M * D);
     bf.t2 = a.get(M * D);
     bf.gst = a.get((size_t)B * 4 * 2);
@@ -1770,7 +1778,10 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         return gemm_ln_on && !ksplit && !bf.l[0].pre && g.math == DDSP_MATH_SPLIT_BF16 && g.B_split && g.A_split && asplit &&
                g.N == D && M >= gemm_ln_min && gemm::res_ln_ok(a);
     };
-    {   // weight preparation, one launch (u2c_prepare_kernel)
+    const int want_state = 1 | (presplit_w ? 2 : 0) | (fuse_glu ? 4 : 0);
+    const bool prepared = bf.wstate && (*bf.wstate & 7) == want_state;
+    const bool p3_ready = prepared && (*bf.wstate & 8);
+    if (!prepared) {   // weight preparation, one launch (u2c_prepare_kernel)
         PrepArgs pa;
         pa.w = w;
         pa.w1 = bf.w1;
@@ -1797,9 +1808,12 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
         PROF(PF_U2C_PREP, 0, 8.0 * (n_w1 + n_w2 + n_wh + 3.0 * 3 * INNER * D + (fuse_glu ? 3.0 * 2 * INNER * D : 0.0) +
                                     (presplit_w ? 6.0 * D * INNER : 0.0)),
              hipLaunchKernelGGL(u2c_prepare_kernel, dim3((unsigned)pa.end[6]), dim3(256), 0, st, pa));
-        if (attn_bf16)   // the three projection matrices as bf16 pieces for the split attention kernels, one launch
-            PROF(PF_U2C_PREP, 0, 3.0 * (4.0 * NF * DH + PERFORMER_P3_BYTES),
-                 performer_p3(st, w.layer[0].proj, w.layer[1].proj, w.layer[2].proj, bf.p3));
+        if (bf.wstate) *bf.wstate = want_state;
+    }
+    if (attn_bf16 && !p3_ready) {   // the three projection matrices as bf16 pieces for the split attention kernels, one launch
+        PROF(PF_U2C_PREP, 0, 3.0 * (4.0 * NF * DH + PERFORMER_P3_BYTES),
+             performer_p3(st, w.layer[0].proj, w.layer[1].proj, w.layer[2].proj, bf.p3));
+        if (bf.wstate) *bf.wstate |= 8;
     }
     // with B_split the GEMM reads ONLY the split copy: both pointers name the same packed matrix
     auto set_b = [&](gemm::Args& g, const float* packed, int a_is_split) {
@@ -2333,13 +2347,54 @@ extern "C" int ddsp_unit2ctrl_fwd(ddsp_ctx* ctx, void* stream, const ddsp_u2c_we
     DDSP_ENTER_DEVICE(ctx);
     const ddsp_u2c_weights w = *wp;
     U2CBufs bf;
+    // prepared-weight slot of the context (ddsp_u2c_weights::version != 0; never while the stream is being captured: a graph
+    // replay must prepare the weights of ITS time)
+    bool cached = false;
+    if (w.version != 0) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) cs = hipStreamCaptureStatusActive;
+        if (cs == hipStreamCaptureStatusNone) {
+            uint64_t key = 1469598103934665603ull;   // FNV-1a over the struct without its counter: pointers and sizes
+            const unsigned char* bytes = (const unsigned char*)&w;
+            for (size_t i = 0; i < offsetof(ddsp_u2c_weights, version); ++i) key = (key ^ bytes[i]) * 1099511628211ull;
+            if (key == 0) key = 1;
+            Arena wdry{ctx, true, 0, 0};
+            plan_weights(wdry, bf, w);
+            if (ctx->wcache_bytes < wdry.total) {
+                // (the stream may still read the old buffer: wait for it before it goes)
+                DDSP_HIP(ctx, hipStreamSynchronize(st));
+                if (ctx->wcache) (void)hipFree(ctx->wcache);
+                ctx->wcache = nullptr;
+                ctx->wcache_bytes = 0;
+                ctx->wcache_key = 0;
+                DDSP_HIP(ctx, hipMalloc((void**)&ctx->wcache, wdry.total));
+                ctx->wcache_bytes = wdry.total;
+            }
+            if (ctx->wcache_key != key || ctx->wcache_version != w.version) {
+                ctx->wcache_key = key;
+                ctx->wcache_version = w.version;
+                ctx->wcache_flags = 0;
+            }
+            Arena wa{ctx, false, 0, 0};
+            wa.ext = ctx->wcache;
+            wa.ext_cap = ctx->wcache_bytes;
+            plan_weights(wa, bf, w);
+            if (wa.rc) return wa.rc;
+            bf.wstate = &ctx->wcache_flags;
+            cached = true;
+        }
+    }
+    // (the arena is sized for a call WITHOUT the slot too: a capture that follows warm-up calls must not have to grow it)
     Arena dry{ctx, true, 0, 0};
-    plan_forward(dry, bf, w, B, Fr, false);
+    {
+        U2CBufs scratch_plan;
+        plan_forward(dry, scratch_plan, w, B, Fr, false, false);
+    }
     rc = ddsp_scratch_reserve_bytes(ctx, dry.total + 4096);
     if (rc) return rc;
     ddsp_scratch_reset(ctx);
     Arena a{ctx, false, 0, 0};
-    plan_forward(a, bf, w, B, Fr, false);
+    plan_forward(a, bf, w, B, Fr, false, cached);
     if (a.rc) return a.rc;
     return u2c_forward(ctx, st, w, in, bf, ctrl);
 }

@@ -8,10 +8,14 @@ Only the non-causal configuration (`c: false`, every shipped config) exists; `c=
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
 import hipddsp
+
+_WEIGHT_CACHE = os.environ.get("DDSP_U2C_WCACHE", "1") != "0"   # measurement aid: 0 = prepare the weights on every forward
 
 NDIM = 256
 N_LAYERS = 3
@@ -210,42 +214,59 @@ class Unit2Control(nn.Module):
             ctx.unit2ctrl_bwd(w, g, units, f0, phase, volume, spk_id, spk_mix_dict, self.n_out, d_ctrl)
         return grads
 
+    def _tensor_slots(self):
+        """(struct field, owning dict, key) for every tensor of `ddsp_u2c_weights`, built once: reading `d[k]` costs a dict
+        lookup where `module.weight` goes through nn.Module.__getattr__ (the walk over the 75 tensors took longer on the host than
+        a B = 1 forward takes on the device).  A Parameter replaced by setattr lands in the same dict and is seen; after replacing
+        a whole SUBMODULE call `rebind()`."""
+        slots = getattr(self, "_slots", None)
+        if slots is None:
+            by_id = {}
+            for mod in self.modules():
+                for d in (mod._parameters, mod._buffers):
+                    for k, t in d.items():
+                        if t is not None:
+                            by_id[id(t)] = (d, k)
+            slots = self._slots = [(name,) + by_id[id(t)] for name, t in self._named_tensors()]
+        return slots
+
+    def rebind(self):
+        """Forget the cached tensor slots / weight struct (after a submodule of this network was replaced)."""
+        self._slots = None
+        self._ws = None
+
     def _weights_struct(self):
+        slots = self._tensor_slots()
+        tensors = [d[k] for _, d, k in slots]
+        grad_mode = torch.is_grad_enabled()
+        key = (grad_mode,) + tuple([(t.data_ptr(), t._version) for t in tensors])
+        ws = getattr(self, "_ws", None)
+        if ws is not None and ws[0] == key:
+            return ws[1], ws[2]
         w = hipddsp.U2CWeights()
         keep = []
-
-        def p(t):
+        for (name, _, _), t in zip(slots, tensors):
             if not t.is_cuda:
                 raise RuntimeError("Unit2Control parameters must live on a HIP device (no CPU fallback)")
             t = t.detach()
             if not t.is_contiguous() or t.dtype != torch.float32:
                 t = t.contiguous().float()
             keep.append(t)
-            return t.data_ptr()
-
-        pre = self.unit_prenet
-        w.prenet_conv1_w, w.prenet_conv1_b = p(pre[1].weight), p(pre[1].bias)
-        w.prenet_gn_w, w.prenet_gn_b = p(pre[2].weight), p(pre[2].bias)
-        w.prenet_conv2_w, w.prenet_conv2_b = p(pre[4].weight), p(pre[4].bias)
-        w.f0_w, w.f0_b = p(self.f0_embed.weight), p(self.f0_embed.bias)
-        w.phase_w, w.phase_b = p(self.phase_embed.weight), p(self.phase_embed.bias)
-        w.volume_w, w.volume_b = p(self.volume_embed.weight), p(self.volume_embed.bias)
-        w.spk_table = p(self.spk_embed.weight)
+            setattr(w, name, t.data_ptr())
         w.n_spk, w.n_unit, w.n_out = self.n_spk, self.n_unit, self.n_out
         w.causal = 1 if self.causal else 0
-        for i, layer in enumerate(self.dec_post[0].net):
-            a, cm = layer.attn, layer.local_mixer.net
-            vals = dict(norm_w=layer.norm.weight, norm_b=layer.norm.bias,
-                        q_w=a.to_q.weight, q_b=a.to_q.bias, k_w=a.to_k.weight, k_b=a.to_k.bias,
-                        v_w=a.to_v.weight, v_b=a.to_v.bias, proj=a.fast_attention.projection_matrix,
-                        out_w=a.to_out.weight, out_b=a.to_out.bias,
-                        cm_ln_w=cm[0].weight, cm_ln_b=cm[0].bias, cm_pw1_w=cm[2].weight, cm_pw1_b=cm[2].bias,
-                        cm_dw_w=cm[4].weight, cm_dw_b=cm[4].bias, cm_pw2_w=cm[6].weight, cm_pw2_b=cm[6].bias)
-            for k, v in vals.items():
-                setattr(w, f"l{i}_{k}", p(v))
-        w.final_ln_w, w.final_ln_b = p(self.dec_post[1].weight), p(self.dec_post[1].bias)
-        head = self.dec_post[2]
-        w.head_g, w.head_v, w.head_b = p(head.weight_g), p(head.weight_v), p(head.bias)
+        # inference: the library may keep its prepared copies of these weights while their values stand (every in-place change of
+        # a tensor - optimizer step, load_state_dict, copy_ - advances its `_version`); training steps prepare them every time
+        # (the nonce tells two model objects apart whose tensors the allocator placed at the same addresses)
+        if grad_mode or not _WEIGHT_CACHE:
+            w.version = 0
+        else:
+            if not hasattr(self, "_weights_nonce"):
+                self._weights_nonce = int.from_bytes(os.urandom(6), "little") << 16
+            w.version = (self._weights_nonce + 1 + sum(int(t._version) for t in tensors)) & ((1 << 64) - 1)
+        # (a copy made by `contiguous().float()` above has a new address every time: such a struct is not worth keeping)
+        if all(a is b or a.data_ptr() == b.data_ptr() for a, b in zip(keep, tensors)):
+            self._ws = (key, w, keep)
         return w, keep
 
     def forward_flat(self, units, f0, phase, volume, spk_id, spk_mix_dict=None):

@@ -19,6 +19,7 @@ COMB_NONE, COMB_SINC, COMB_SINC_GATED = 0, 1, 2
 FIR_ALLPASS, FIR_DYNAMIC, FIR_STATIC = 0, 1, 2
 EXC_AUDIO, EXC_UNIT_NOISE, EXC_GENERATE = 0, 1, 2
 FIR_FP32, FIR_SPLIT_BF16 = 0, 3   # ddsp_ltv_fir `math` (include/ddsp_amd.h)
+ABI_VERSION = 5                   # DDSP_ABI_VERSION of include/ddsp_amd.h (struct layouts: U2CWeights)
 MATH_FP32, MATH_SPLIT_BF16 = 0, 3  # ddsp_ctx_set_math
 ATTENTION_CAUSAL = 200            # ddsp_performer_attention: causal_linear_attention (pcmer.py:170-188)
 
@@ -37,6 +38,7 @@ class U2CWeights(_c.Structure):
             "norm_w", "norm_b", "q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "proj", "out_w", "out_b",
             "cm_ln_w", "cm_ln_b", "cm_pw1_w", "cm_pw1_b", "cm_dw_w", "cm_dw_b", "cm_pw2_w", "cm_pw2_b")]
         + [(n, _vp) for n in ("final_ln_w", "final_ln_b", "head_g", "head_v", "head_b")]
+        + [("version", _c.c_uint64)]     # change counter of the weight values (0: prepare the weights on every call)
     )
 
 
@@ -140,6 +142,9 @@ def load_library():
                 fn = getattr(lib, name)   # AttributeError if the symbol is not exported
                 fn.restype = res
                 fn.argtypes = args
+            if lib.ddsp_abi_version() != ABI_VERSION:
+                raise RuntimeError(f"{LIB_PATH} has ABI version {lib.ddsp_abi_version()}, this binding needs {ABI_VERSION}: "
+                                   "rebuild it (`python ddsp-svc-official_amd/hipddsp/build.py`)")
             _lib = lib
     return _lib
 

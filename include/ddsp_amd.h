@@ -136,6 +136,13 @@ typedef struct ddsp_u2c_weights {
     int causal;   /* 0 = the shipped configs (`c: false`); 1 = causal convolutions + causal linear attention */
     ddsp_u2c_layer layer[3];
     const float *final_ln_w, *final_ln_b, *head_g, *head_v, *head_b;
+    /* The caller's change counter of the weight VALUES, or 0.  ddsp_unit2ctrl_fwd prepares the weights for its kernels on every
+     * call (weight norm of the head, re-ordered pw1 rows, bf16 hi/lo copies: two launches, ~1.5 % of a 64-clip forward).  With
+     * version != 0 it keeps the prepared copies in the context and reuses them while every pointer and integer of this struct
+     * AND the version are what they were - so bump it whenever a tensor's contents change (torch: the sum of the parameters'
+     * `_version` counters does that).  Ignored while the stream is being captured into a HIP graph (a replay must see the
+     * weights of its own time) and by the training entry points. */
+    uint64_t version;
 } ddsp_u2c_weights;
 
 /* replaces ddsp/unit2control.py:68-101 `Unit2Control.forward` + ddsp/pcmer.py (non-causal, c=False only).

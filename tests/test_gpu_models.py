@@ -561,3 +561,38 @@ def test_combsubfast_shipped_encoder_widths(dev, lib_path, n_unit, B):
     assert sig.shape == (B, Fr * HOP) and torch.isfinite(sig).all()
     err = rms(sig[:nb].cpu() - sig_o)
     assert err < GATE, (n_unit, B, err, rms(sig_o))
+
+
+def test_prepared_weight_cache_follows_the_weights(dev, lib_path):
+    """Inference keeps the control network's prepared weights (weight norm, re-ordered / bf16 copies) in the context between
+    calls (`ddsp_u2c_weights::version`): an in-place change of a parameter, a load_state_dict and a second model on the same
+    context must each be seen by the next forward - bit for bit what a fresh context computes."""
+    import hipddsp
+    B, Fr = 4, 40
+    inp = _to(synthetic.make_inputs(5, B, Fr, with_noise=False), dev)
+    phase = torch.zeros(B, Fr, device=dev)
+
+    def run(model):
+        with torch.no_grad():
+            return model.unit2ctrl.forward_flat(inp["units"], inp["f0"], phase, inp["volume"], inp["spk_id"], None).clone()
+
+    def fresh(model):   # the same forward with preparation forced (grad mode on: version 0)
+        with torch.enable_grad():
+            w, keep = model.unit2ctrl._weights_struct()
+            assert w.version == 0
+            ctx = hipddsp.context_for(dev)
+            return ctx.unit2ctrl(w, inp["units"], inp["f0"], phase, inp["volume"], inp["spk_id"], None, model.unit2ctrl.n_out).clone()
+
+    m1, _ = synthetic.build_model("CombSub", seed=21, device=dev)
+    m2, _ = synthetic.build_model("CombSub", seed=22, device=dev)
+    a1 = run(m1)
+    assert torch.equal(a1, run(m1)) and torch.equal(a1, fresh(m1))            # second call: cached copies
+    a2 = run(m2)
+    assert torch.equal(a2, fresh(m2)) and not torch.equal(a1, a2)
+    assert torch.equal(run(m1), a1)                                            # back to the first model
+    with torch.no_grad():
+        m1.unit2ctrl.dec_post[2].weight_g.mul_(1.5)                            # in place: `_version` advances
+    b1 = run(m1)
+    assert not torch.equal(b1, a1) and torch.equal(b1, fresh(m1))
+    m1.load_state_dict(m2.state_dict())
+    assert torch.equal(run(m1), a2)

@@ -35,7 +35,8 @@ def test_struct_layouts_match_header():
     import ctypes
     import hipddsp
     n_ptr = 13 + 3 * 19 + 5
-    assert ctypes.sizeof(hipddsp.U2CWeights) == 8 * n_ptr + 16       # 3 ints padded to 16
+    assert ctypes.sizeof(hipddsp.U2CWeights) == 8 * n_ptr + 16 + 8   # 4 ints, the 64-bit change counter (ABI 5)
+    assert hipddsp.U2CWeights.version.offset == 8 * n_ptr + 16 and hipddsp.load_library().ddsp_abi_version() == hipddsp.ABI_VERSION
     assert ctypes.sizeof(hipddsp.ProfEntry) == 4 + 36 + 8 + 3 * 8
 
 
