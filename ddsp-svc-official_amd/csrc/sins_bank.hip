@@ -9,6 +9,8 @@
 // Bound: fp32 vector ALU (H*7 FLOP per sample vs 4*H/hop + 8 B per sample of HBM traffic).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int RESEED = 32;
@@ -165,6 +167,76 @@ __global__ void __launch_bounds__(256) sins_bank_bwd_partial_kernel(const float*
     }
 }
 
+// The same partial sums for hop <= 512 and H % 32 == 0 (round 3): the kernel above reduces every harmonic's two sums across the
+// wave on its own (2 x 6 shuffle steps per harmonic: more instructions than the 12 of the products and the rotation).  Here a
+// lane keeps the 2 x 32 partial sums of a re-seed block in registers and the wave reduces them TOGETHER by a transposing
+// butterfly - at step m (32, 16, ..., 1) a lane sends the half of its values its partner keeps and adds the half it keeps, so 64
+// values cost 63 exchanges instead of 64 x 6, and lane l ends with the wave's total of value l (l >> 5: window share, l & 31:
+// harmonic of the block).  Same sums, different order of the additions.
+__global__ void __launch_bounds__(256) sins_bank_bwd_partial32_kernel(const float* __restrict__ phase, const float* __restrict__ dout,
+                                                                      int H, int Fr, int hop, float* __restrict__ partial) {
+    __shared__ float red[4][64];
+    const int m = blockIdx.x, b = blockIdx.y;
+    const int64_t row = (int64_t)b * Fr + m;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv_hop = 1.0f / (float)hop;
+    float ph[2], g0[2], g1[2], s1[2], c1[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = threadIdx.x + 256 * i;
+        ph[i] = 0.f;
+        g0[i] = 0.f;
+        g1[i] = 0.f;
+        if (j < hop) {
+            const int64_t t = row * hop + j;
+            ph[i] = phase[t];
+            const float d = dout[t], w1 = (float)j * inv_hop;
+            g0[i] = (1.0f - w1) * d;
+            g1[i] = w1 * d;
+        }
+        sincosf(ph[i], &s1[i], &c1[i]);
+    }
+    for (int k0 = 0; k0 < H; k0 += 32) {
+        float zs[2], zc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) sincosf(__fmul_rn(ph[i], (float)(k0 + 1)), &zs[i], &zc[i]);
+        float a[64];
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a0 = fmaf(g0[i], zs[i], a0);
+                a1 = fmaf(g1[i], zs[i], a1);
+                const float nc = fmaf(zc[i], c1[i], -zs[i] * s1[i]);
+                const float ns = fmaf(zs[i], c1[i], zc[i] * s1[i]);
+                zc[i] = nc;
+                zs[i] = ns;
+            }
+            a[kk] = a0;
+            a[32 + kk] = a1;
+        }
+        // transposing butterfly over the 64 lanes
+#pragma unroll
+        for (int mbit = 32, c = 32; mbit >= 1; mbit >>= 1, c >>= 1) {
+            const bool upper = (lane & mbit) != 0;
+#pragma unroll
+            for (int i = 0; i < c; ++i) {
+                const float send = upper ? a[i] : a[i + c];
+                const float keep = upper ? a[i + c] : a[i];
+                a[i] = keep + __shfl_xor(send, mbit, 64);
+            }
+        }
+        red[wave][lane] = a[0];
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int which = threadIdx.x >> 5, kk = threadIdx.x & 31;
+            partial[(row * 2 + which) * H + k0 + kk] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void __launch_bounds__(256) sins_bank_bwd_combine_kernel(const float* __restrict__ ctrl, int64_t ld, int H,
                                                                     const float* __restrict__ f0_frames,
                                                                     const float* __restrict__ partial, int64_t rows,
@@ -224,8 +296,17 @@ extern "C" int ddsp_sins_bank_bwd(ddsp_ctx* ctx, void* stream, const float* ctrl
     float* partial = nullptr;
     if ((rc = ddsp_scratch_get(ctx, pf * sizeof(float), (void**)&partial))) return rc;
     ddsp_prof_begin(ctx, st, PF_SINS_BANK);
-    hipLaunchKernelGGL(sins_bank_bwd_partial_kernel, dim3((unsigned)Fr, (unsigned)B), dim3(256),
-                       8 * n_harmonics * sizeof(float), st, phase, d_out, n_harmonics, (int)Fr, hop, partial);
+    static int bwd32 = -1;   // DDSP_SINS_BWD32=0: the per-harmonic reduction at every shape (measurement aid)
+    if (bwd32 < 0) {
+        const char* e = getenv("DDSP_SINS_BWD32");
+        bwd32 = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (bwd32 && hop <= 512 && n_harmonics % 32 == 0)
+        hipLaunchKernelGGL(sins_bank_bwd_partial32_kernel, dim3((unsigned)Fr, (unsigned)B), dim3(256), 0, st, phase, d_out,
+                           n_harmonics, (int)Fr, hop, partial);
+    else
+        hipLaunchKernelGGL(sins_bank_bwd_partial_kernel, dim3((unsigned)Fr, (unsigned)B), dim3(256),
+                           8 * n_harmonics * sizeof(float), st, phase, d_out, n_harmonics, (int)Fr, hop, partial);
     int64_t blocks = ceil_div64(rows * n_harmonics, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(sins_bank_bwd_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ctrl, ctrl_ld, n_harmonics,
