@@ -2145,6 +2145,66 @@ __global__ void __launch_bounds__(256) reduce_partials_2d_kernel(const float* __
         out[(i / C) * ldo + coff + (i % C)] = s;
     }
 }
+// Deferred reductions (round 3): the 18 Linear layers of the three blocks write their split partial sums (and those of their bias
+// column sums) into regions of their own and ONE launch at the end of the backward pass adds them all up - 36 launches of 5-6 us
+// fewer per training step.  Same order of the additions (z ascending) as reduce_partials_2d_kernel.
+constexpr int RED_JOBS_MAX = 48;
+struct RedJobs {
+    int n;
+    const float* src[RED_JOBS_MAX];
+    float* dst[RED_JOBS_MAX];
+    int nz[RED_JOBS_MAX], O[RED_JOBS_MAX], C[RED_JOBS_MAX];
+    int ldo[RED_JOBS_MAX];
+    int bend[RED_JOBS_MAX];   // exclusive end of the job's range of workgroups
+};
+__global__ void __launch_bounds__(256) reduce_jobs_kernel(RedJobs J) {
+    int j = 0;
+    while (j + 1 < J.n && (int)blockIdx.x >= J.bend[j]) ++j;
+    const int b0 = j ? J.bend[j - 1] : 0, nb = J.bend[j] - b0;
+    const float* __restrict__ partial = J.src[j];
+    float* __restrict__ out = J.dst[j];
+    const int nz = J.nz[j], C = J.C[j];
+    const int64_t n = (int64_t)J.O[j] * C, ldo = J.ldo[j];
+    for (int64_t i = (int64_t)((int)blockIdx.x - b0) * 256 + threadIdx.x; i < n; i += (int64_t)nb * 256) {
+        float s = 0.f;
+        for (int z = 0; z < nz; ++z) s += partial[(int64_t)z * n + i];
+        out[(i / C) * ldo + (i % C)] = s;
+    }
+}
+struct WgDefer {
+    RedJobs jobs;
+    float* pool;
+    size_t used, cap;   // floats
+    float* take(size_t n) {
+        n = (n + 63) & ~(size_t)63;
+        if (used + n > cap) return nullptr;
+        float* p = pool + used;
+        used += n;
+        return p;
+    }
+    bool push(const float* src, float* dst, int nz, int O, int C, int64_t ldo) {
+        if (jobs.n >= RED_JOBS_MAX) return false;
+        const int j = jobs.n++;
+        jobs.src[j] = src;
+        jobs.dst[j] = dst;
+        jobs.nz[j] = nz;
+        jobs.O[j] = O;
+        jobs.C[j] = C;
+        jobs.ldo[j] = (int)ldo;
+        int64_t blocks = ((int64_t)O * C + 1023) / 1024;       // four outputs per thread
+        if (blocks > 256) blocks = 256;
+        if (blocks < 1) blocks = 1;
+        jobs.bend[j] = (j ? jobs.bend[j - 1] : 0) + (int)blocks;
+        return true;
+    }
+};
+static void flush_deferred(hipStream_t st, WgDefer& df) {
+    if (df.jobs.n == 0) return;
+    hipLaunchKernelGGL(reduce_jobs_kernel, dim3((unsigned)df.jobs.bend[df.jobs.n - 1]), dim3(256), 0, st, df.jobs);
+    df.jobs.n = 0;
+    df.used = 0;
+}
+
 constexpr int WG_SPLITS = 16;
 static int wgrad(ddsp_ctx* ctx, hipStream_t st, const float* dY, int64_t ldy, int O, const float* X, int64_t ldx, int C,
                  int64_t M, float* partial, float* out, int64_t ldo, int coff) {
@@ -2225,7 +2285,7 @@ static int wgrad_tile_choice() {
 }
 static int layer_grads(ddsp_ctx* ctx, hipStream_t st, const float* dY, int64_t ldy, int O, const float* X, int64_t ldx, int C,
                        int taps, int Fr, int64_t M, float* wpart, float* cpart, float* xs, float* w_out, int64_t ldo,
-                       float* b_out, int tap_shift = 0) {   // tap_shift: 0 centred taps, -1 causal taps (taps == 3 only)
+                       float* b_out, int tap_shift = 0, WgDefer* defer = nullptr) {   // tap_shift: 0 centred taps, -1 causal taps (taps == 3 only)
     int rc;
     const bool split = ctx->math == DDSP_MATH_SPLIT_BF16 && (taps == 1 || C % 128 == 0);
     if (!split) {
@@ -2252,9 +2312,21 @@ static int layer_grads(ddsp_ctx* ctx, hipStream_t st, const float* dY, int64_t l
     g.Fr = Fr;
     g.M = M;
     g.chunk = wgrad::chunk_for(M, WG_SPLITS);
-    g.partial = wpart;
-    g.bias_partial = b_out ? cpart : nullptr;
     const int nz = wgrad::splits_for(M, g.chunk), N = taps * C;
+    // deferred: partial sums into regions of the caller's pool, added up by ONE launch at the end of the backward pass
+    float* dpart = nullptr;
+    float* dbias = nullptr;
+    if (defer && defer->jobs.n + 2 <= RED_JOBS_MAX) {
+        const size_t u0 = defer->used;
+        dpart = defer->take((size_t)nz * O * N);
+        dbias = b_out ? defer->take((size_t)nz * O) : nullptr;
+        if (!dpart || (b_out && !dbias)) {
+            defer->used = u0;
+            dpart = dbias = nullptr;
+        }
+    }
+    g.partial = dpart ? dpart : wpart;
+    g.bias_partial = b_out ? (dpart ? dbias : cpart) : nullptr;
     ddsp_prof_begin(ctx, st, PF_U2C_BWD);
     int tile = wgrad_tile_choice();
     // 64x64 tiles: with 16 splits every layer of the network gives 512-1280 workgroups; the larger tiles stage less per
@@ -2265,8 +2337,13 @@ static int layer_grads(ddsp_ctx* ctx, hipStream_t st, const float* dY, int64_t l
     else if (tile == 21) wgrad::launch<2, 1>(st, g);
     else if (tile == 12) wgrad::launch<1, 2>(st, g);
     else wgrad::launch<1, 1>(st, g);
-    hipLaunchKernelGGL(reduce_partials_2d_kernel, dim3(grid_for((int64_t)O * N)), dim3(256), 0, st, wpart, nz, O, N, w_out, ldo, 0);
-    if (b_out) hipLaunchKernelGGL(reduce_partials_kernel, dim3((O + 63) / 64), dim3(256), 0, st, cpart, nz, (int64_t)O, b_out);
+    if (dpart) {
+        defer->push(dpart, w_out, nz, O, N, ldo);
+        if (b_out) defer->push(dbias, b_out, nz, 1, O, O);
+    } else {
+        hipLaunchKernelGGL(reduce_partials_2d_kernel, dim3(grid_for((int64_t)O * N)), dim3(256), 0, st, wpart, nz, O, N, w_out, ldo, 0);
+        if (b_out) hipLaunchKernelGGL(reduce_partials_kernel, dim3((O + 63) / 64), dim3(256), 0, st, cpart, nz, (int64_t)O, b_out);
+    }
     ddsp_prof_end(ctx, st, 2.0 * M * O * (double)N, 4.0 * M * (O + C));
     DDSP_LAUNCH_CHECK(ctx);
     return DDSP_OK;
@@ -2411,7 +2488,9 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
     // ---- arena: kept forward activations + backward temporaries ----
     U2CBufs bf;
     float *ctrl = nullptr, *dX, *dA, *dB512, *dC512, *dV512, *dG1, *dQF, *dKF, *dcx, *dks, *dD, *coefq, *coefk, *gx, *wpart, *cpart,
-        *dWh, *pk, *xs, *dwpart, *gbst, *w2t, *wts;
+        *dWh, *pk, *xs, *dwpart, *gbst, *w2t, *wts, *wpool;
+    // partial sums of the 18 Linear layers of the blocks, reduced by one launch at the end (WgDefer): 17 splits at most
+    const size_t wpool_floats = (size_t)(WG_SPLITS + 1) * 3 * ((size_t)2 * D * INNER + (size_t)2 * INNER * D + (size_t)3 * INNER * D + 2 * D + 2 * INNER + 3 * INNER + 1024);
     auto plan_bwd = [&](Arena& a) {
         if (!keep) {
             plan_forward(a, bf, w, B, Fr, true);
@@ -2441,6 +2520,7 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
         gbst = a.get((size_t)B * 4 * 2);
         w2t = a.get((size_t)D * 3 * D);
         wts = a.get((size_t)NO * D + 3 * ((size_t)2 * D * INNER + (size_t)2 * INNER * D + (size_t)3 * INNER * D));
+        wpool = a.get(wpool_floats);
     };
     if (keep) {
         Arena k{ctx, false, 0, 0, (char*)keep, keep_bytes};
@@ -2491,6 +2571,15 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
         static_assert(TS_MAX >= 19, "table too small");
         hipLaunchKernelGGL(transpose_split_kernel, dim3(64, n), dim3(256), 0, st, ts);
     }
+    WgDefer df{};
+    df.pool = wpool;
+    df.cap = wpool_floats;
+    static int defer_on = -1;   // DDSP_WGRAD_DEFER=0: every layer's partial sums reduced right behind its product (measurement aid)
+    if (defer_on < 0) {
+        const char* e = getenv("DDSP_WGRAD_DEFER");
+        defer_on = (e && e[0] == '0') ? 0 : 1;
+    }
+    WgDefer* const dfp = defer_on ? &df : nullptr;
     // ---- head: ctrl = LN(x) W^T + b, W = g v/|v| ----
     if ((rc = layer_grads(ctx, st, d_ctrl, NO, NO, bf.y_final, D, D, 1, (int)Fr, M, wpart, cpart, xs, dWh, D, G(head_b)))) return rc;
     hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((NO + 3) / 4), dim3(256), 0, st, w.head_g, w.head_v, dWh, NO, D,
@@ -2506,7 +2595,7 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
 #define GLP(p) const_cast<float*>(GL.p)
         // ===== conv module: x_out = x_mid + pw2(silu(dw(glu(pw1(LN(x_mid)))))) =====
         if ((rc = layer_grads(ctx, st, dX, D, D, b.dwo, INNER, INNER, 1, (int)Fr, M, wpart, cpart, xs, GLP(cm_pw2_w), INNER,
-                              GLP(cm_pw2_b)))) return rc;
+                              GLP(cm_pw2_b), 0, dfp))) return rc;
         dgrad(st, dX, D, L.cm_pw2_w, D, INNER, M, dB512, false, wt_pw2[l]);                                  // d_dwo
         hipLaunchKernelGGL(silu_bwd_kernel, dim3(grid_for(M * INNER)), dim3(256), 0, st, b.pre, dB512, M * INNER, dB512);  // d_pre
         {
@@ -2520,7 +2609,7 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
                            dim3(256), 0, st, dB512, L.cm_dw_w, nullptr, (int)B, (int)Fr, dC512, nullptr, DWK, 1, w.causal ? 0 : DWK / 2, 0);   // d_glu (adjoint taps: left' = DWK - 1 - left)
         hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for(M * INNER)), dim3(256), 0, st, b.g1, dC512, M, dG1);
         if ((rc = layer_grads(ctx, st, dG1, 2 * INNER, 2 * INNER, b.y2, D, D, 1, (int)Fr, M, wpart, cpart, xs, GLP(cm_pw1_w), D,
-                              GLP(cm_pw1_b)))) return rc;
+                              GLP(cm_pw1_b), 0, dfp))) return rc;
         dgrad(st, dG1, 2 * INNER, L.cm_pw1_w, 2 * INNER, D, M, dA, false, wt_pw1[l]);                         // d_y2
         hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(rows_g), dim3(256), 0, st, b.x_mid, L.cm_ln_w, dA, dX, M, dX, gx);
         if ((rc = colsum_pair(ctx, st, gx, dA, D, M, D, cpart, GLP(cm_ln_w), GLP(cm_ln_b)))) return rc;
@@ -2528,7 +2617,7 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
 
         // ===== attention: x_mid = x_in + to_out(attn) =====
         if ((rc = layer_grads(ctx, st, dX, D, D, b.attn, INNER, INNER, 1, (int)Fr, M, wpart, cpart, xs, GLP(out_w), INNER,
-                              GLP(out_b)))) return rc;
+                              GLP(out_b), 0, dfp))) return rc;
         dgrad(st, dX, D, L.out_w, D, INNER, M, dB512, false, wt_out[l]);                                       // d_attn
         // the two K = 64 adjoint products of the attention (both operands K-contiguous, one problem per (utterance, head)): on the
         // LDS-DMA kernel in the context's arithmetic (round 3; the register-staged fp32 kernel took 51 us each at B = 32)
@@ -2607,7 +2696,7 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
         float* gw[3] = {GLP(q_w), GLP(k_w), GLP(v_w)};
         float* gb[3] = {GLP(q_b), GLP(k_b), GLP(v_b)};
         for (int i = 0; i < 3; ++i) {
-            if ((rc = layer_grads(ctx, st, dqkv[i], INNER, INNER, b.y, D, D, 1, (int)Fr, M, wpart, cpart, xs, gw[i], D, gb[i]))) return rc;
+            if ((rc = layer_grads(ctx, st, dqkv[i], INNER, INNER, b.y, D, D, 1, (int)Fr, M, wpart, cpart, xs, gw[i], D, gb[i], 0, dfp))) return rc;
             dgrad(st, dqkv[i], INNER, pw[i], INNER, D, M, dA, i > 0, wt_qkv[l][i]);                               // d_y (summed)
         }
         hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(rows_g), dim3(256), 0, st, b.x_in, L.norm_w, dA, dX, M, dX, gx);
@@ -2665,6 +2754,8 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
                           G(prenet_conv1_b), w.causal ? -1 : 0))) return rc;
     hipLaunchKernelGGL(unpack_conv3_kernel, dim3(grid_for((int64_t)D * w.n_unit * 3)), dim3(256), 0, st, pk, D, w.n_unit,
                        G(prenet_conv1_w));
+    // the deferred partial sums of the blocks' Linear layers, one launch
+    PROF(PF_U2C_BWD, 0, 4.0 * df.used, flush_deferred(st, df));
     DDSP_LAUNCH_CHECK(ctx);
 #undef G
     return DDSP_OK;
