@@ -162,6 +162,7 @@ class _SynthTrainFn(torch.autograd.Function):
         finally:
             ctx.set_math(keep_math)
         fctx.model, fctx.dsp = model, ctx
+        fctx.set_materialize_grads(False)   # outputs the loss does not use arrive as None in backward, not as zero tensors to add
         fctx.args = (units, f0_frames, volume, spk_id, spk_mix_dict, nargs, ps["phase_frames"])
         fctx.saved = (ctrl, saved, kept)
         phase_out = ps["phase"] if model._front_wants.get("want_phase") else ps["phase_frames"]
