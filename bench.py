@@ -214,7 +214,8 @@ def realtime_mode(args, model, dev, dist, world, rank):
     import realtime
     import synthetic
     sr, block_time = SR, 0.2
-    r = realtime.StreamRenderer(model, sr, block_time, 0.04, dev, buffer_num=4, threshold_db=-60.0, spk_id=1, use_graph=True)
+    use_graph = os.environ.get("DDSP_RT_GRAPH", "1") != "0"     # measurement aid: 0 = eager launches instead of the graph replay
+    r = realtime.StreamRenderer(model, sr, block_time, 0.04, dev, buffer_num=4, threshold_db=-60.0, spk_id=1, use_graph=use_graph)
     feats = [{k: v.to(dev) for k, v in synthetic.make_inputs(9000 + 17 * rank + i, 1, r.frames, with_noise=False).items()}
              for i in range(8)]
     g = torch.Generator(device=dev).manual_seed(11 + rank)
