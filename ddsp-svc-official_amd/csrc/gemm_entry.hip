@@ -128,12 +128,12 @@ extern "C" int ddsp_gemm_res_ln(ddsp_ctx* ctx, void* stream, const float* A_spli
                                 const float* res, const float* gamma, const float* beta, int M, int K, float* X, float* Y,
                                 int y_split) {
     DDSP_REQUIRE(ctx, ctx && A_split && W_split && bias && res && gamma && beta && X && Y, "ddsp_gemm_res_ln: null argument");
-    gemm::LnArgs a{A_split, W_split, K, K, M, K, bias, res, X, gamma, beta, Y, y_split ? 1 : 0};
+    gemm::LnArgs a{A_split, W_split, K, K, M, K, bias, res, X, gamma, beta, Y, (y_split & 1) ? 1 : 0};   // y_split bit 1 (value 2): A is fp32 rows
     DDSP_REQUIRE(ctx, M >= 1 && K >= 64 && gemm::res_ln_ok(a), "ddsp_gemm_res_ln: K % 32 == 0, K >= 64, 16-byte aligned operands");
     hipStream_t st = (hipStream_t)stream;
     DDSP_ENTER_DEVICE(ctx);
     ddsp_prof_begin(ctx, st, PF_OTHER);
-    DDSP_HIP(ctx, gemm::launch_res_ln(st, a));
+    DDSP_HIP(ctx, gemm::launch_res_ln(st, a, (y_split & 2) == 0));
     ddsp_prof_end(ctx, st, 2.0 * M * 256.0 * K, 4.0 * M * (K + 4.0 * 256));
     DDSP_LAUNCH_CHECK(ctx);
     return DDSP_OK;

@@ -25,7 +25,7 @@
 namespace gemm {
 
 struct LnArgs {
-    const float* A;       // (M, K) pre-split rows
+    const float* A;       // (M, K) rows: pre-split, or fp32 (launch_res_ln(..., a_split = false))
     const float* W;       // (256, K) pre-split rows
     int64_t lda, ldw;     // row pitches in floats
     int M, K;             // K % 32 == 0
@@ -42,7 +42,9 @@ constexpr int LN_BM = 64, LN_N = 256, LN_NS = 4;   // 4 x 40 KB = the whole LDS:
 constexpr int LN_STAGE = (LN_BM + LN_N) * 32;                 // floats per stage: 40 KB
 constexpr size_t LN_LDS_BYTES = (size_t)LN_NS * LN_STAGE * sizeof(float);
 
-template <int NS, int RB>   // NS ring stages; RB row blocks of 32 per wave: 1 = 16 waves (2 x 8 grid), 2 = 8 waves (each both row blocks)
+// NS ring stages; RB row blocks of 32 per wave: 1 = 16 waves (2 x 8 grid), 2 = 8 waves (each both row blocks); ASPLIT: A arrives in
+// the pre-split layout (else fp32 rows, split into bf16 hi / lo per fragment in the loop like kernel_dma's mode 7: the same bits)
+template <int NS, int RB, bool ASPLIT>
 __global__ void __launch_bounds__(1024 / RB) kernel_res_ln(LnArgs g) {
     extern __shared__ __attribute__((aligned(1024))) float ln_lds[];
     float* const lds = ln_lds;
@@ -141,7 +143,27 @@ __global__ void __launch_bounds__(1024 / RB) kernel_res_ln(LnArgs g) {
             const bf16x8 wh = __builtin_bit_cast(bf16x8, wv[2 * half]), wl = __builtin_bit_cast(bf16x8, wv[2 * half + 1]);
 #pragma unroll
             for (int b = 0; b < RB; ++b) {
-                const bf16x8 xh = __builtin_bit_cast(bf16x8, xv[b][2 * half]), xl = __builtin_bit_cast(bf16x8, xv[b][2 * half + 1]);
+                bf16x8 xh, xl;
+                if constexpr (ASPLIT) {
+                    xh = __builtin_bit_cast(bf16x8, xv[b][2 * half]);
+                    xl = __builtin_bit_cast(bf16x8, xv[b][2 * half + 1]);
+                } else {
+                    // kernel_dma's split of a lane's 8 k-values: round to nearest even twice, two values per conversion
+                    typedef float f32x2p __attribute__((ext_vector_type(2)));
+                    typedef __bf16 bf16x2p __attribute__((ext_vector_type(2)));
+                    ddsp_u32x4 wh_, wl_;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const f32x4& src = d < 2 ? xv[b][2 * half] : xv[b][2 * half + 1];
+                        f32x2p r = {src[(2 * d) & 3], src[(2 * d + 1) & 3]};
+                        const uint32_t hh = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2p));
+                        wh_[d] = hh;
+                        r = r - (f32x2p){__builtin_bit_cast(float, hh << 16), __builtin_bit_cast(float, hh & 0xffff0000u)};
+                        wl_[d] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2p));
+                    }
+                    xh = __builtin_bit_cast(bf16x8, wh_);
+                    xl = __builtin_bit_cast(bf16x8, wl_);
+                }
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[b], 0, 0, 0);
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc[b], 0, 0, 0);
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[b], 0, 0, 0);
@@ -231,7 +253,7 @@ inline bool res_ln_ok(const LnArgs& g) {
              (uintptr_t)g.beta | (uintptr_t)g.Y) % 16) == 0;
 }
 
-template <int RB>
+template <int RB, bool ASPLIT>
 inline hipError_t launch_res_ln_rb(hipStream_t st, const LnArgs& g) {
     static std::atomic<uint64_t> done{0};   // devices on which the dynamic-LDS attribute has been set
     int dev = 0;
@@ -239,20 +261,22 @@ inline hipError_t launch_res_ln_rb(hipStream_t st, const LnArgs& g) {
     if (e != hipSuccess) return e;
     const uint64_t bit = 1ull << (dev & 63);
     if (!(done.load(std::memory_order_acquire) & bit)) {
-        e = hipFuncSetAttribute((const void*)kernel_res_ln<LN_NS, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LN_LDS_BYTES);
+        e = hipFuncSetAttribute((const void*)kernel_res_ln<LN_NS, RB, ASPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LN_LDS_BYTES);
         if (e != hipSuccess) return e;
         done.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((kernel_res_ln<LN_NS, RB>), dim3((unsigned)((g.M + LN_BM - 1) / LN_BM)), dim3(1024 / RB), LN_LDS_BYTES, st, g);
+    hipLaunchKernelGGL((kernel_res_ln<LN_NS, RB, ASPLIT>), dim3((unsigned)((g.M + LN_BM - 1) / LN_BM)), dim3(1024 / RB), LN_LDS_BYTES, st, g);
     return hipSuccess;
 }
-inline hipError_t launch_res_ln(hipStream_t st, const LnArgs& g) {
+// a_split: A is in the pre-split layout (else fp32 rows)
+inline hipError_t launch_res_ln(hipStream_t st, const LnArgs& g, bool a_split = true) {
     static int rb = -1;     // DDSP_GEMM_LN_RB=1: sixteen waves of one 32 x 32 block each (measurement aid)
     if (rb < 0) {
         const char* e = getenv("DDSP_GEMM_LN_RB");
         rb = (e && e[0] == '1') ? 1 : 2;
     }
-    return rb == 1 ? launch_res_ln_rb<1>(st, g) : launch_res_ln_rb<2>(st, g);
+    if (!a_split) return launch_res_ln_rb<2, false>(st, g);
+    return rb == 1 ? launch_res_ln_rb<1, true>(st, g) : launch_res_ln_rb<2, true>(st, g);
 }
 
 }  // namespace gemm

@@ -1767,15 +1767,18 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
     static int64_t gemm_ln_min = -1;   // DDSP_GEMM_LN_MIN: rows from which the fused kernel runs (measurement aid)
     if (gemm_ln_min < 0) {
         const char* e = getenv("DDSP_GEMM_LN_MIN");
-        gemm_ln_min = e ? atoll(e) : 2048;
+        // (measured: B = 8 / 1376 rows 0.476 -> 0.519 ms, B = 24 / 4128 rows 0.826 -> 0.839 ms per forward WITH the fused kernel -
+        // a few workgroups each pull 640 KB of operands through one CU's load path; B = 64 / 11008 rows 1.138 -> 1.126)
+        gemm_ln_min = e ? atoll(e) : 8192;
     }
     bool ln_done = false;   // the next LayerNorm's output has been written by the producer of its input
     auto ln_args = [&](const gemm::Args& g, const float* x_res, float* x_dst, const float* bias, const float* gamma,
                        const float* beta, float* y_out) {
-        return gemm::LnArgs{g.A, g.B_split, g.lda, g.ldb, g.M, g.K, bias, x_res, x_dst, gamma, beta, y_out, 1};
+        return gemm::LnArgs{g.A, g.B_split, g.lda, g.ldb, g.M, g.K, bias, x_res, x_dst, gamma, beta, y_out, asplit};
     };
+    // (the A operand pre-split at large batches, fp32 below; small batches keep the separate LayerNorm, which sums their K-split partials)
     auto ln_fusable = [&](const gemm::Args& g, const gemm::LnArgs& a) {
-        return gemm_ln_on && !ksplit && !bf.l[0].pre && g.math == DDSP_MATH_SPLIT_BF16 && g.B_split && g.A_split && asplit &&
+        return gemm_ln_on && !ksplit && !bf.l[0].pre && g.math == DDSP_MATH_SPLIT_BF16 && g.B_split && (g.A_split || !asplit) &&
                g.N == D && M >= gemm_ln_min && gemm::res_ln_ok(a);
     };
     const int want_state = 1 | (presplit_w ? 2 : 0) | (fuse_glu ? 4 : 0);
@@ -2007,7 +2010,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
             set_b(g, bf.wout + (size_t)l * D * INNER, attn_bf16 ? asplit : 0);
             const gemm::LnArgs la = ln_args(g, b.x_in, b.x_mid, L.out_b, L.cm_ln_w, L.cm_ln_b, b.y2);
             if (ln_fusable(g, la)) {
-                PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * D * INNER, 4.0 * M * (INNER + 4 * D), DDSP_HIP(ctx, gemm::launch_res_ln(st, la)));
+                PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * D * INNER, 4.0 * M * (INNER + 4 * D), DDSP_HIP(ctx, gemm::launch_res_ln(st, la, g.A_split != 0)));
                 ln_done = true;
                 ln_src = b.x_mid;
             } else
@@ -2073,7 +2076,7 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
             float* n_y = l + 1 < 3 ? bf.l[l + 1].y : bf.y_final;
             const gemm::LnArgs la = ln_args(g, b.x_mid, b.x_out, L.cm_pw2_b, n_g, n_b, n_y);
             if (ln_fusable(g, la)) {
-                PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * D * INNER, 4.0 * M * (INNER + 4 * D), DDSP_HIP(ctx, gemm::launch_res_ln(st, la)));
+                PROF(PF_U2C_GEMM_LINEAR, 2.0 * M * D * INNER, 4.0 * M * (INNER + 4 * D), DDSP_HIP(ctx, gemm::launch_res_ln(st, la, g.A_split != 0)));
                 ln_done = true;
                 ln_src = b.x_out;
             } else

@@ -482,13 +482,14 @@ class Context:
                   (CONV_X_SPLIT if x_split else 0) | (CONV_ACT_SPLIT if act_split else 0))
         return out if act_slope is None else (out, act)
 
-    def gemm_res_ln(self, A_split, W_split, bias, res, gamma, beta, y_split=True):
-        """X = res + A W^T + bias and Y = LayerNorm(X) * gamma + beta in one launch; A (M, K) and W (256, K) pre-split."""
+    def gemm_res_ln(self, A_split, W_split, bias, res, gamma, beta, y_split=True, a_fp32=False):
+        """X = res + A W^T + bias and Y = LayerNorm(X) * gamma + beta in one launch; W (256, K) pre-split, A (M, K) pre-split or
+        (a_fp32) plain fp32 rows."""
         M, K = A_split.shape
         X = torch.empty(M, 256, device=A_split.device, dtype=torch.float32)
         Y = torch.empty(M, 256, device=A_split.device, dtype=torch.float32)
         self.call("ddsp_gemm_res_ln", _ptr(A_split), _ptr(W_split), _ptr(bias), _ptr(res), _ptr(gamma), _ptr(beta), int(M), int(K),
-                  _ptr(X), _ptr(Y), 1 if y_split else 0)
+                  _ptr(X), _ptr(Y), (1 if y_split else 0) | (2 if a_fp32 else 0))
         return X, Y
 
     def conv1d_pair_supported(self, C, ktaps, dil):

@@ -356,7 +356,7 @@ int ddsp_gemm_f32(ddsp_ctx* ctx, void* stream, const float* A, int64_t lda, int 
 /* The fused building block of the control network's residual Linear layers (pcmer.py:221-251 `to_out`, :42-63 pw2) at large
  * batches: X = res + A W^T + bias (M x 256; X may be res) and Y = LayerNorm(X) * gamma + beta (eps 1e-5) in one launch.
  * A (M x K) and W (256 x K) are in the pre-split operand layout (per 8 consecutive k: 8 bf16 hi, then 8 bf16 lo); Y is
- * written in that layout too (y_split != 0) or as fp32.  Same bits as ddsp_gemm_f32 on split operands followed by the
+ * written in that layout too (y_split & 1) or as fp32; y_split & 2: A is given as plain fp32 rows and split in the kernel.  Same bits as ddsp_gemm_f32 on split operands followed by the
  * LayerNorm kernel.  Exposed for tests. */
 int ddsp_gemm_res_ln(ddsp_ctx* ctx, void* stream, const float* A_split, const float* W_split, const float* bias,
                      const float* res, const float* gamma, const float* beta, int M, int K, float* X, float* Y, int y_split);

@@ -139,6 +139,12 @@ def test_residual_layernorm_kernel(ctx, dev, M, K):
     for _ in range(2):
         X3, Y3 = ctx.gemm_res_ln(As, Ws, bias, res, gamma, beta, y_split=True)
         assert torch.equal(X3, X) and torch.equal(Y3, Y)
+    # A as fp32 rows, split in the kernel (the form mid-size batches run): the hi + lo pieces it forms are the ones _split_layout made
+    # (same values; where x lies exactly between two bf16 numbers the in-kernel split may pick the other high part, so sums agree to
+    # rounding, not to the bit)
+    X4, Y4 = ctx.gemm_res_ln(Av.float().contiguous(), Ws, bias, res, gamma, beta, y_split=False, a_fp32=True)
+    assert float((X4 - X).abs().max()) < 2e-6 * max(1.0, float(want.abs().max()))
+    assert float((Y4 - Y2).abs().max()) < 1e-5 * max(1.0, float(ln.abs().max()))
     if K >= 32 * 13:     # (the wave-specialised kernel's residual form, itself bit-identical to kernel_dma: needs 13 k-steps)
         assert torch.equal(ctx.gemm(As, Ws, bias, tile=75, variant=8 + 16, out=res.clone()), X)
 
@@ -152,16 +158,17 @@ def test_residual_layernorm_in_the_model_is_bit_identical(dev, lib_path):
         "import torch, hipddsp, synthetic;"
         "dev = torch.device('cuda:0');"
         "model, cfg = synthetic.build_model('CombSub', seed=5, device=dev);"
-        "inp = {k: v.to(dev) for k, v in synthetic.make_inputs(11, 32, 172, with_noise=False).items()};"
+        "inp = {k: v.to(dev) for k, v in synthetic.make_inputs(11, int(os.environ.get('LN_TEST_B', '32')), 172, with_noise=False).items()};"
         "ctx = hipddsp.context_for(dev);"
         "ps = ctx.phase_scan(inp['f0'], 512, 44100);"
         "ctrl = model.unit2ctrl.forward_flat(inp['units'], inp['f0'], ps['phase_frames'], inp['volume'], inp['spk_id'], None);"
         "print(hashlib.sha256(ctrl.cpu().numpy().tobytes()).hexdigest())"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    digests = []
-    for flag in ("1", "0"):
-        env = dict(os.environ, DDSP_GEMM_LN=flag)
-        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-        assert out.returncode == 0, out.stderr[-2000:]
-        digests.append(out.stdout.strip().splitlines()[-1])
-    assert digests[0] == digests[1], digests
+    for nb in ("32", "8"):      # pre-split activations / fp32 activations split in the kernel
+        digests = []
+        for flag in ("1", "0"):
+            env = dict(os.environ, DDSP_GEMM_LN=flag, LN_TEST_B=nb, DDSP_GEMM_LN_MIN="512")   # (default: from 8192 rows)
+            out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+            assert out.returncode == 0, out.stderr[-2000:]
+            digests.append(out.stdout.strip().splitlines()[-1])
+        assert digests[0] == digests[1], (nb, digests)
