@@ -796,6 +796,15 @@ inline int64_t t128_min() {
 //                                       64x64 / 4 waves for small or skinny problems.
 // Larger tiles raise FLOP per staged byte (the L2->LDS operand stream, ~4-6 TB/s chip-wide, is what caps these
 // K=256..768 shapes near 85 TFLOP/s) but leave CUs idle at 11008 = 2*43*128 rows; see DESIGN.md section 9.
+inline bool half_tiles() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("DDSP_GEMM_HALF_TILES");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 // DDSP_GEMM_TAIL_CUT=1 (measurement aid, off): with the XCD-aware order too, the few tiles of a last, nearly empty round are cut
 // out of the launch and run as quadrant tiles in a second one.  Measured at the bench shape (QKV: 1032 = 2 x 512 + 8 tiles):
 // Linear family 0.361 -> 0.372 ms - the eight tail tiles run alone on their CUs and take about what the second launch costs.
@@ -817,7 +826,10 @@ inline void launch(hipStream_t st, const Args& g, int batch, const Epi& epi) {
         // implicit-im2col convs (N = 256): the 4-wave 64x64 DMA tile with one source pointer per tap
         if (dma_ok(g) && g.zeros && g.Cin % 32 == 0 && g.Cin + 32 <= DDSP_ZERO_FLOATS && g.N <= 256) {
             // (also for a few tiles: see the small-problem note below)
-            dma_go<64, 64, Epi, 3, 4, A_CONV3>(st, g, batch, epi);
+            if (half_tiles() && blocks(64, 64) < 128 && blocks(64, 64) > 16)
+                dma_go<32, 64, Epi, 4, 2, A_CONV3>(st, g, batch, epi);
+            else
+                dma_go<64, 64, Epi, 3, 4, A_CONV3>(st, g, batch, epi);
             return;
         }
     }
@@ -829,6 +841,13 @@ inline void launch(hipStream_t st, const Args& g, int batch, const Epi& epi) {
         if (small_dma < 0) {
             const char* e = getenv("DDSP_GEMM_SMALL_DMA");
             small_dma = (e && e[0] == '0') ? 0 : 1;
+        }
+        // Fewer than half the CUs busy with 64x64 tiles (B = 8: 1376 rows x 256 columns = 88 tiles): what bounds a workgroup
+        // there is its CU's operand load path, so 32x64 tiles on two waves - twice the workgroups, 3/4 of the bytes each - finish
+        // sooner although they stage more in total.  DDSP_GEMM_HALF_TILES=0 restores 64x64 (measurement aid).
+        if (small_dma && half_tiles() && dma_ok(g) && blocks(64, 64) < 128 && blocks(64, 64) > 16 && g.K >= 256) {
+            dma_go<32, 64, Epi, 4, 2>(st, g, batch, epi);
+            return;
         }
         if (small_dma && dma_ok(g) && blocks(64, 64) < 256 && g.K >= 256) {
             static int small_ns = -1;

@@ -596,3 +596,32 @@ def test_prepared_weight_cache_follows_the_weights(dev, lib_path):
     assert not torch.equal(b1, a1) and torch.equal(b1, fresh(m1))
     m1.load_state_dict(m2.state_dict())
     assert torch.equal(run(m1), a2)
+
+
+@pytest.mark.parametrize("causal", [0, 1])
+def test_tiled_depthwise_convolution_matches_the_register_kernel(dev, lib_path, causal):
+    """The LDS-tiled depthwise convolution of the large-batch forward (64 frames x 64 channels per workgroup) adds the same taps in
+    the same order as the register-window kernel it replaced: the control matrices agree bit for bit, centred and causal taps
+    (DDSP_DW_PAIR 3 / 1, read once per process: child processes)."""
+    import subprocess, sys, os
+    code = (
+        "import sys, os, hashlib; sys.path.insert(0, os.path.join(%r, 'ddsp-svc-official_amd'));"
+        "import torch, hipddsp, synthetic;"
+        "from ddsp.vocoder import CombSub;"
+        "dev = torch.device('cuda:0');"
+        "model, cfg = synthetic.build_model('CombSub', seed=5, device=dev);"
+        "mc = CombSub(44100, 512, cfg['n_mag_allpass'], cfg['n_mag_harmonic'], cfg['n_mag_noise'], 256, cfg['n_spk'], c=bool(%d));"
+        "mc.load_state_dict(model.state_dict(), strict=True); mc = mc.to(dev).eval();"
+        "inp = {k: v.to(dev) for k, v in synthetic.make_inputs(11, 48, 172, with_noise=False).items()};"
+        "ps = hipddsp.context_for(dev).phase_scan(inp['f0'], 512, 44100);"
+        "ctrl = mc.unit2ctrl.forward_flat(inp['units'], inp['f0'], ps['phase_frames'], inp['volume'], inp['spk_id'], None);"
+        "assert torch.isfinite(ctrl).all();"
+        "print(hashlib.sha256(ctrl.cpu().numpy().tobytes()).hexdigest())"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), causal)
+    digests = []
+    for flag in ("3", "1"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DDSP_DW_PAIR=flag), capture_output=True, text=True,
+                             timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append(out.stdout.strip().splitlines()[-1])
+    assert digests[0] == digests[1], digests
