@@ -47,6 +47,34 @@ def fo_to_rot(fo, sr, initial_phase=None, precise=False):
     return out["rot"].to(fo.dtype)
 
 
+_IRDFT_TABLES = {}
+
+
+def _irfft(spectra):
+    """Inverse real DFT of (..., n_mag) complex spectra, n = 2 (n_mag - 1), as ONE product on the library's fp32 MFMA GEMM
+    (`ddsp_gemm_f32`; round 3 - until then `torch.fft.irfft`, i.e. rocFFT, was the one vendor-library call behind this API):
+        h[t] = (1/n) [ Re X_0 + (-1)^t Re X_{n/2} + 2 sum_{0<k<n/2} (Re X_k cos(2 pi k t / n) - Im X_k sin(2 pi k t / n)) ]
+    (the imaginary parts of the first and last bin do not enter, as in `irfft`).  The table is made once per size in fp64."""
+    n_mag = spectra.shape[-1]
+    n = 2 * (n_mag - 1)
+    dev = spectra.device
+    key = (n_mag, dev)
+    tab = _IRDFT_TABLES.get(key)
+    if tab is None:
+        t = torch.arange(n, device=dev, dtype=torch.float64)[:, None]
+        k = torch.arange(n_mag, device=dev, dtype=torch.float64)[None, :]
+        c = torch.full((1, n_mag), 2.0, device=dev, dtype=torch.float64)
+        c[0, 0] = c[0, -1] = 1.0
+        ang = (t * k % n) * (2.0 * torch.pi / n)              # exact argument reduction: t * k is an integer below 2^53
+        tab = torch.cat([c * torch.cos(ang), -c * torch.sin(ang)], dim=1) / n
+        tab[:, n_mag] = 0.0                                   # sin terms of the first and last bin
+        tab[:, -1] = 0.0
+        tab = _IRDFT_TABLES[key] = tab.float().contiguous()  # (n, 2 n_mag): the GEMM's [N][K] operand
+    a = torch.cat([spectra.real, spectra.imag], dim=-1).reshape(-1, 2 * n_mag).float().contiguous()
+    h = context_for(dev).gemm(a, tab)                         # (`ddsp_gemm_f32`: fp32 products whatever the context's mode)
+    return h.reshape(*spectra.shape[:-1], n)
+
+
 def _impulse_response(magnitudes, hann_window=True, half_width_frames=None):
     """Frequency responses (B, Frame, n_mag) complex -> causal impulse responses (B, Frame, n = 2*(n_mag-1)).
 
@@ -56,10 +84,10 @@ def _impulse_response(magnitudes, hann_window=True, half_width_frames=None):
       * static window:   w = periodic Hann of length n  (window and response are both rotated by n/2 there)
       * dynamic window:  x = (i - n/2) / half_width;  x > 1 is set to 0 BEFORE the raised cosine (so the weight is 1,
                          not 0) and x < -1 is not clamped - both as the reference does it.
-    Device ops of PyTorch (rocFFT inverse real FFT + elementwise); the models never call this - their filters come
-    from `ddsp_fir_from_ctrl`, which fuses the activations and the inverse DFT into one MFMA GEMM.
+    The inverse DFT is a product on the library's GEMM (`_irfft`), the rest elementwise device ops; the models never call this -
+    their filters come from `ddsp_fir_from_ctrl`, which fuses the activations and the inverse DFT into one MFMA GEMM.
     """
-    h = torch.fft.irfft(magnitudes)
+    h = _irfft(magnitudes)
     n = h.shape[-1]
     i = torch.arange(n, device=h.device)
     g = h.index_select(-1, (i - n // 2) % n)
@@ -76,7 +104,7 @@ def frequency_filter(audio, magnitudes, hann_window=True, half_width_frames=None
     """Linear time-varying FIR filtering from per-frame frequency responses (reference `ddsp/core.py:331-336`).
 
     audio :: (B, T) device tensor, magnitudes :: (B, Frame, n_mag) complex, half_width_frames :: (B, Frame, 1) or None.
-    The impulse responses are formed with device ops of PyTorch (`_impulse_response`), the filtering itself -
+    The impulse responses are formed by `_impulse_response` (inverse DFT on the library's GEMM + elementwise ops), the filtering itself -
     `_fft_convolve`, `core.py:190-238`: 50 %-overlapped Bartlett frames, one filter per frame, output delayed by
     n/2 and cropped to T - is the hand-written `ddsp_ltv_fir` kernel.  That kernel supports what the models use:
     T = Frame * 512 and even filter lengths 32..2046 (n_mag 17..1024); other shapes raise ValueError.  Forward only:
