@@ -9,6 +9,8 @@
 #include "gemm_f32.h"
 #include "tables.h"
 
+#include <stdlib.h>
+
 namespace {
 
 // One wavefront per frame row.  REAL modes: out[f] = exp(ctrl[f]) * scale.
@@ -102,6 +104,103 @@ struct EpiMirrorStore {  // row[k] = row[n-k] = acc
     }
 };
 
+
+// The same activations with several consecutive bins per lane (round 3): the kernel above gives a lane ONE bin per pass, so every
+// value of a split row costs an 8-lane exchange and every store is 4 bytes - 41 us per step for its three launches, at 0.53 of
+// the vector-issue rate.  REAL modes: 8 bins per lane (two 16-byte loads, the split group formed in the lane, two 16-byte stores).
+__global__ void __launch_bounds__(256) fir_act_exp8_kernel(float scale, const float* __restrict__ ctrl, int64_t ld, int M, int ldo,
+                                                           int64_t rows, float* __restrict__ out, int split) {
+    const int per_row = M / 8;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * per_row) return;
+    const int64_t row = i / per_row;
+    const int gq = (int)(i % per_row);
+    const float* src = ctrl + row * ld + 8 * gq;
+    const f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[e] = expf(a[e]) * scale;      // (/128 is an exact scaling)
+        v[4 + e] = expf(b[e]) * scale;
+    }
+    float* dst = out + row * ldo + 8 * gq;
+    if (split) {
+        ddsp_u32x4 hi, lo;
+        ddsp_split8(v, hi, lo);
+        *(ddsp_u32x4*)dst = hi;
+        *(ddsp_u32x4*)(dst + 4) = lo;
+    } else {
+        *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+}
+
+// ALLPASS with 4 bins per lane: gd = pi tanh(ctrl), phi = the fp64 running sum rounded to fp32 per bin (ATen's CPU cumsum), out =
+// [cos phi | sin phi].  A lane sums its four increments in fp64, the wave scans the lane totals once (row shifts and broadcasts of
+// the two halves of the fp64 value), chunks of 256 bins carry on.  One wavefront per row.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double act_dpp_d(double v) {
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __builtin_bit_cast(double, ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+__global__ void __launch_bounds__(256) fir_act_allpass4_kernel(const float* __restrict__ ctrl, int64_t ld, int M, int ldo, int64_t rows,
+                                                               float* __restrict__ out, int split) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* src = ctrl + row * ld;
+    float* dst = out + row * ldo;
+    const float pi_f = 3.14159274101257324f;
+    double carry = 0.0;
+    for (int f0 = 0; f0 < M; f0 += 256) {
+        const int f = f0 + 4 * lane;                    // M % 8 == 0: a lane's four bins are all inside the row or all outside
+        const bool in = f < M;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (in) x = *(const f32x4*)(src + f);
+        double run = 0.0, loc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gd = in ? __fmul_rn(pi_f, tanhf(x[e])) : 0.f;
+            run += (double)gd;
+            loc[e] = run;
+        }
+        double incl = run;
+        incl += act_dpp_d<0x111, 0xf>(incl);
+        incl += act_dpp_d<0x112, 0xf>(incl);
+        incl += act_dpp_d<0x114, 0xf>(incl);
+        incl += act_dpp_d<0x118, 0xf>(incl);
+        incl += act_dpp_d<0x142, 0xa>(incl);
+        incl += act_dpp_d<0x143, 0xc>(incl);
+        const double base = carry + (incl - run);
+        f32x4 c, sn;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float phi = (float)(base + loc[e]);
+            float s_ = 0.f, c_ = 0.f;
+            if (in) sincosf(phi, &s_, &c_);
+            c[e] = c_;
+            sn[e] = s_;
+        }
+        {
+            const uint64_t u = __builtin_bit_cast(uint64_t, incl);
+            const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)u, 63), hi = __builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), 63);
+            carry += __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+        }
+        if (split) {
+            // lanes 2j, 2j + 1 own one group of 8 bins (every lane takes part in the exchange)
+            const ddsp_u32x4 pc = ddsp_split4_pair(c, (lane & 1) != 0, 1), ps = ddsp_split4_pair(sn, (lane & 1) != 0, 1);
+            if (in) {
+                *(ddsp_u32x4*)(dst + f) = pc;
+                *(ddsp_u32x4*)(dst + M + f) = ps;
+            }
+        } else if (in) {
+            *(f32x4*)(dst + f) = c;
+            *(f32x4*)(dst + M + f) = sn;
+        }
+    }
+}
 
 // ---- backward -----------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) dyn_window_scale_kernel(float* __restrict__ d_ir, const float* __restrict__ f0,
@@ -215,8 +314,21 @@ extern "C" int ddsp_fir_from_ctrl(ddsp_ctx* ctx, void* stream, int mode, const f
     // operands already split (the DMA kernel is certain at these sizes; B = B_split makes a fallback fail loudly)
     const bool presplit = tap_major && tab_split && rows >= 8192 && M % 8 == 0 && ctx->math != 4;
     ddsp_prof_begin(ctx, st, PF_FIR_ACT);
-    hipLaunchKernelGGL(fir_act_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, mode, ctrl, ctrl_ld, M,
-                       lda, rows, act, presplit ? 1 : 0);
+    static int act_wide = -1;   // DDSP_FIR_ACT_WIDE=0: one bin per lane and pass at every shape (measurement aid)
+    if (act_wide < 0) {
+        const char* e = getenv("DDSP_FIR_ACT_WIDE");
+        act_wide = (e && e[0] == '0') ? 0 : 1;
+    }
+    const bool wide = act_wide && M % 8 == 0 && ctrl_ld % 4 == 0 && lda % 8 == 0 && ((uintptr_t)ctrl % 16) == 0;
+    if (wide && mode != DDSP_FIR_ALLPASS)
+        hipLaunchKernelGGL(fir_act_exp8_kernel, dim3((unsigned)ceil_div64(rows * (M / 8), 256)), dim3(256), 0, st,
+                           mode == DDSP_FIR_STATIC ? 1.0f / 128.0f : 1.0f, ctrl, ctrl_ld, M, lda, rows, act, presplit ? 1 : 0);
+    else if (wide)
+        hipLaunchKernelGGL(fir_act_allpass4_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, ctrl, ctrl_ld, M, lda, rows,
+                           act, presplit ? 1 : 0);
+    else
+        hipLaunchKernelGGL(fir_act_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, mode, ctrl, ctrl_ld, M,
+                           lda, rows, act, presplit ? 1 : 0);
     ddsp_prof_end(ctx, st, 0.0, 4.0 * rows * (M + K));
     DDSP_LAUNCH_CHECK(ctx);
     ddsp_prof_begin(ctx, st, PF_FIR_DFT_GEMM);
