@@ -259,6 +259,15 @@ extern "C" int ddsp_rss_loss(ddsp_ctx* ctx, void* stream, const float* x_pred, c
         loss_math = e ? atoi(e) : 0;
     }
 
+    // The adjoint contraction dXf = dX T^T is a LINEAR map of the spectral gradient: a 4e-6 product error there is a 4e-6 relative
+    // error of the gradient, nothing is amplified (unlike the forward spectra, whose error meets 1 / S) - it runs in the context's
+    // arithmetic (split-bf16 by default; DDSP_LOSS_BWD_MATH=0 forces fp32 products, ddsp_ctx_set_math(FP32) does too).
+    static int loss_bwd_env = -2;
+    if (loss_bwd_env == -2) {
+        const char* e = getenv("DDSP_LOSS_BWD_MATH");
+        loss_bwd_env = e ? atoi(e) : -1;
+    }
+    const int loss_bwd_math = loss_bwd_env >= 0 ? loss_bwd_env : (ctx->math == DDSP_MATH_FP32 ? 0 : DDSP_MATH_SPLIT_BF16);
     ddsp_prof_begin(ctx, st, PF_RSS_LOSS);
     double flops = 0.0;
     for (int s = 0; s < n_scale; ++s) {
@@ -291,7 +300,7 @@ extern "C" int ddsp_rss_loss(ddsp_ctx* ctx, void* stream, const float* x_pred, c
             // per-frame gradient dXf = dX x T^T (A = dX (M x Kb), B(k, n) = tab[n][k]) into the framed buffer, then the
             // overlap-add back onto the signal axis
             gemm::Args gb = gemm::make(Xp, Kb, tab, Kb, (int)M, N, Kb);
-            gb.math = loss_math;
+            gb.math = loss_bwd_math;
             gemm::EpiStore eg{Xf, Kp, nullptr, 1, 0, 0};
             gemm::launch<true, true, gemm::A_PLAIN>(st, gb, 1, eg);
             hipLaunchKernelGGL(frames_ola_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(B * T, 256), 16384)), dim3(256), 0,
