@@ -203,6 +203,21 @@ __global__ void __launch_bounds__(256) fir_act_allpass4_kernel(const float* __re
 }
 
 // ---- backward -----------------------------------------------------------------------------------------------
+// rows of n floats (n even: 8-byte aligned) -> rows of ld >= n floats, zero beyond n
+__global__ void __launch_bounds__(256) repack_rows_kernel(const float* __restrict__ src, int n, int64_t rows, int ld,
+                                                          float* __restrict__ dst) {
+    typedef float f32x2r __attribute__((ext_vector_type(2)));
+    const int half = ld / 2;
+    const int64_t total = rows * half;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / half;
+        const int k = 2 * (int)(i % half);
+        f32x2r v = {0.f, 0.f};
+        if (k < n) v = *(const f32x2r*)(src + m * n + k);
+        *(f32x2r*)(dst + m * ld + k) = v;
+    }
+}
+
 __global__ void __launch_bounds__(256) dyn_window_scale_kernel(float* __restrict__ d_ir, const float* __restrict__ f0,
                                                                int n, int64_t rows, float sr15) {
     const int64_t total = rows * n;
@@ -377,11 +392,23 @@ extern "C" int ddsp_fir_from_ctrl_bwd(ddsp_ctx* ctx, void* stream, int mode, con
     const int M = n_mag, n = 2 * (n_mag - 1);
     const int K = (mode == DDSP_FIR_ALLPASS) ? 2 * M : M;
     const int lda = ddsp_pad4(K);
-    int rc = ddsp_scratch_reserve_bytes(ctx, (size_t)rows * lda * sizeof(float) + 4096);
+    // The contraction over the n taps (510 / 1022: rows of d_ir are not 16-byte aligned) is a linear map of the gradient: with
+    // split-bf16 products allowed it runs on the LDS-DMA kernel from a copy of d_ir with the table's row pitch (512 / 1024, zero
+    // pad columns) instead of the register-staged fp32 kernel.  DDSP_FIR_BWD_DMA=0: the fp32 kernel (measurement aid)
+    static int bwd_dma = -1;
+    if (bwd_dma < 0) {
+        const char* e = getenv("DDSP_FIR_BWD_DMA");
+        bwd_dma = (e && e[0] == '0') ? 0 : 1;
+    }
+    const int ldp = ddsp_pad4(n);
+    const bool repack = bwd_dma && ctx->math != DDSP_MATH_FP32 && ldp % 32 == 0 && rows >= 1024;
+    int rc = ddsp_scratch_reserve_bytes(ctx, (size_t)rows * (lda + (repack ? ldp : 0)) * sizeof(float) + 8192);
     if (rc) return rc;
     ddsp_scratch_reset(ctx);
     float* d_act = nullptr;
     if ((rc = ddsp_scratch_get(ctx, (size_t)rows * lda * sizeof(float), (void**)&d_act))) return rc;
+    float* d_pad = nullptr;
+    if (repack && (rc = ddsp_scratch_get(ctx, (size_t)rows * ldp * sizeof(float), (void**)&d_pad))) return rc;
     float* tab = nullptr;
     const int kind = mode == DDSP_FIR_ALLPASS ? TAB_IRDFT_CPLX : (mode == DDSP_FIR_STATIC ? TAB_IRDFT_RE_HANN : TAB_IRDFT_RE);
     if ((rc = ddsp_get_table(ctx, st, kind, M, 0, &tab))) return rc;
@@ -393,9 +420,18 @@ extern "C" int ddsp_fir_from_ctrl_bwd(ddsp_ctx* ctx, void* stream, int mode, con
                            1.5f * (float)sr);
     }
     // d_act[m][f] = sum_k d_ir[m][k] * T[f][k]
-    gemm::Args g = gemm::make(d_ir, n, tab, ddsp_pad4(n), (int)rows, K, n);
     gemm::EpiStore e{d_act, lda, nullptr, 1, 0, 0};
-    gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e);
+    if (repack) {
+        int64_t blocks = ceil_div64(rows * (ldp / 2), 256);
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(repack_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_ir, n, rows, ldp, d_pad);
+        gemm::Args g = gemm::make(d_pad, ldp, tab, ldp, (int)rows, K, ldp);
+        g.math = DDSP_MATH_SPLIT_BF16;
+        gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e);
+    } else {
+        gemm::Args g = gemm::make(d_ir, n, tab, ddsp_pad4(n), (int)rows, K, n);
+        gemm::launch<true, true, gemm::A_PLAIN>(st, g, 1, e);
+    }
     hipLaunchKernelGGL(fir_act_bwd_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, mode, ctrl, ctrl_ld, M,
                        d_act, lda, rows, d_ctrl, d_ctrl_ld);
     ddsp_prof_end(ctx, st, 2.0 * rows * (double)n * K, 4.0 * rows * (2.0 * K + n));
