@@ -79,15 +79,28 @@ struct EpiDynWindow {
     int n;
     const float* f0;  // per row
     float sr15;       // 1.5 * sr as fp32
+    int fast;         // split-bf16 products (taps carry ~4e-6 anyway): the window by one reciprocal per row and v_cos_f32 (~1e-6 of
+                      // the weight) instead of two IEEE divisions and cosf per tap - the epilogue was 0.53 of the launch's vector issue
     __device__ __forceinline__ float col(int) const { return 0.f; }
+    __device__ __forceinline__ float window_fast(float inv_hw, int k) const {
+        float w = (float)(k - n / 2) * inv_hw;
+        if (w > 1.0f) w = 0.0f;
+        return fmaf(0.5f, __builtin_amdgcn_cosf(0.5f * w), 0.5f);      // cos(pi w): v_cos_f32 takes revolutions
+    }
     __device__ __forceinline__ float window(float hw, int k) const {
         float w = __fdiv_rn((float)(k - n / 2), hw);
         if (w > 1.0f) w = 0.0f;
         return __fdiv_rn(__fadd_rn(1.0f, cosf(__fmul_rn(3.14159274101257324f, w))), 2.0f);
     }
     __device__ __forceinline__ void operator()(int, int m, int k, float v, float) const {
-        const float hw = __fdiv_rn(sr15, __fadd_rn(f0[m], 1e-3f));
         float* row = ir + (int64_t)m * n;
+        if (fast) {
+            const float inv_hw = __fdiv_rn(__fadd_rn(f0[m], 1e-3f), sr15);
+            row[k] = v * window_fast(inv_hw, k);
+            if (k > 0 && k < n / 2) row[n - k] = v * window_fast(inv_hw, n - k);
+            return;
+        }
+        const float hw = __fdiv_rn(sr15, __fadd_rn(f0[m], 1e-3f));
         row[k] = __fmul_rn(v, window(hw, k));
         if (k > 0 && k < n / 2) row[n - k] = __fmul_rn(v, window(hw, n - k));
     }
@@ -296,6 +309,15 @@ __global__ void __launch_bounds__(256) fir_act_bwd_kernel(int mode, const float*
 }  // namespace
 
 
+static bool dyn_fast() {   // DDSP_FIR_DYN_FAST=0: the exact window arithmetic in every mode (measurement aid)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("DDSP_FIR_DYN_FAST");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 extern "C" int ddsp_fir_from_ctrl(ddsp_ctx* ctx, void* stream, int mode, const float* ctrl, int64_t ctrl_ld,
                                   int n_mag, const float* f0_frames, int64_t rows, int sr, float* ir) {
     DDSP_REQUIRE(ctx, ctx && ctrl && ir, "ddsp_fir_from_ctrl: null argument");
@@ -369,7 +391,7 @@ extern "C" int ddsp_fir_from_ctrl(ddsp_ctx* ctx, void* stream, int mode, const f
         // even filter: taps 0..n/2 from the GEMM, the rest mirrored by the epilogue
         gemm::Args g = gemm::make(act, lda, tab, ldb, (int)rows, n / 2 + 1, K);
         if (mode == DDSP_FIR_DYNAMIC)
-            run(g, EpiDynWindow{ir, n, f0_frames, 1.5f * (float)sr});
+            run(g, EpiDynWindow{ir, n, f0_frames, 1.5f * (float)sr, (tap_major && ctx->math != DDSP_MATH_FP32 && dyn_fast()) ? 1 : 0});
         else
             run(g, EpiMirrorStore{ir, n});
     }
