@@ -394,7 +394,12 @@ __global__ void __launch_bounds__(WS_THREADS) kernel_ws(Args g, Epi epi, int til
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float a = acc[prev][i][0][4 * rg + r] + bgate[prev][0], gt = acc[prev][i][1][4 * rg + r] + bgate[prev][1];
-                x[r] = a * (1.0f / (1.0f + expf(-gt)));
+                // split-bf16 products (values carry ~4e-6): sigmoid by v_exp_f32 / v_rcp_f32 (~2 ulp) instead of expf and an IEEE
+                // division - 0.44 of this launch's vector issue was the epilogue; fp32 products keep the exact form
+                if constexpr (MATH != 0)
+                    x[r] = a * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * gt));
+                else
+                    x[r] = a * (1.0f / (1.0f + expf(-gt)));
                 acc[prev][i][0][4 * rg + r] = 0.f;
                 acc[prev][i][1][4 * rg + r] = 0.f;
             }
