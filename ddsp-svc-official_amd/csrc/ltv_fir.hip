@@ -34,13 +34,24 @@ constexpr int IRPAD = 32;
 constexpr int SEG = 4;          // segments (hops) per block: 8 wavefronts, one 256-sample tile each; 2 blocks per CU by LDS
 
 __device__ __forceinline__ float noise_u(uint64_t seed, uint64_t idx) {
-    // splitmix64 finaliser of a counter: stateless, so every block that needs sample idx regenerates it
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    float u = (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);  // 24-bit U[0,1) like torch.rand fp32
-    return u * 2.0f - 1.0f;                                       // exact in fp32
+    // A stateless hash of the sample counter (every block that needs sample idx regenerates it).  Round 3: two rounds of a 32-bit
+    // integer finaliser (multiply / xor-shift, constants of the "lowbias32" family) instead of the splitmix64 finaliser - its three
+    // 64 x 64-bit multiplies were ~45 vector instructions per sample in the FIR kernel's staging waves, which regenerate every
+    // sample twice (50 % overlapped frames); this is ~16.  The high words of counter and seed enter between the rounds.
+    uint32_t x = (uint32_t)idx ^ (uint32_t)seed;
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    x += (uint32_t)(idx >> 32) * 0x9E3779B9u + (uint32_t)(seed >> 32);
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    const float u = (float)(x >> 8) * (1.0f / 16777216.0f);   // 24-bit U[0,1) like torch.rand fp32
+    return u * 2.0f - 1.0f;                                   // exact in fp32
 }
 
 // acc[s] += sum_{q=qa..qb} A_q * B_q for the four k-steps s of a 16x16x16 Toeplitz-block product:
