@@ -21,15 +21,20 @@ def host_ms(fn, n=50):
     return (t1 - t0) / n * 1e3
 
 
-def timeit(fn, n=20, warm=3):
+def timeit(fn, n=20, warm=3, rounds=3):
+    """Seconds per call: the MEDIAN of `rounds` timed rounds of n calls each.  (One round of 20 calls is at the mercy of a single
+    stall - an allocator call, a first touch: two evidence sessions of round 3 each had one entry 2-3x off that a rerun did not show.)"""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n
+    ts = []
+    for _ in range(rounds):
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / n)
+    return sorted(ts)[len(ts) // 2]
 
 B, Fr = 64, 172
 for name in ("CombSub", "Sins256", "CombSubFast", "Sins"):
