@@ -36,6 +36,39 @@ struct LnArgs {
     const float* beta;    // [256]
     float* Y;             // (M, 256): LayerNorm(X) as split groups (y_split) or fp32
     int y_split;
+    // A_CONV3 (implicit im2col of a 3-tap "same" convolution, k = tap * Cin + c, Cin % 32 == 0): frames per utterance, input
+    // channels, tap shift (0 centred, -1 causal) and a page of >= Cin + 32 zero floats for the taps that fall off an utterance
+    int Fr = 1, Cin = 32, tap_shift = 0;
+    const float* zeros = nullptr;
+};
+
+// What is added to the product before the LayerNorm: the default - bias and the residual rows, fetched before the k loop
+struct PreResidual {
+    struct State {
+        f32x4 res[2][4];
+        f32x4 bias4[4];
+    };
+    template <int RB>
+    __device__ __forceinline__ void load(State& s, const LnArgs& g, int m0, int rg0, int lr, int cg, int lh) const {
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const int row_m = m0 + 32 * (rg0 + b) + lr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s.res[b][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (row_m < g.M) s.res[b][q] = *(const f32x4*)(g.res + (int64_t)row_m * 256 + 32 * cg + 8 * q + 4 * lh);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s.bias4[q] = *(const f32x4*)(g.bias + 32 * cg + 8 * q + 4 * lh);
+    }
+    // x piece of row m (clamped into range by the caller), columns c0 .. c0 + 3 = group q of the lane; acc = the product
+    __device__ __forceinline__ f32x4 apply(const State& s, const LnArgs&, int b, int q, int, int, f32x4 acc) const {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = s.res[b][q][e] + (acc[e] + s.bias4[q][e]);
+        return v;
+    }
 };
 
 constexpr int LN_BM = 64, LN_N = 256, LN_NS = 4;   // 4 x 40 KB = the whole LDS: three k-steps in flight
@@ -44,8 +77,10 @@ constexpr size_t LN_LDS_BYTES = (size_t)LN_NS * LN_STAGE * sizeof(float);
 
 // NS ring stages; RB row blocks of 32 per wave: 1 = 16 waves (2 x 8 grid), 2 = 8 waves (each both row blocks); ASPLIT: A arrives in
 // the pre-split layout (else fp32 rows, split into bf16 hi / lo per fragment in the loop like kernel_dma's mode 7: the same bits)
-template <int NS, int RB, bool ASPLIT>
-__global__ void __launch_bounds__(1024 / RB) kernel_res_ln(LnArgs g) {
+// A_MODE: A_PLAIN or A_CONV3 (the loader moves an A row's source by the tap's frame offset, or to the zero page); Pre: what joins the
+// product before the LayerNorm (PreResidual; unit2ctrl.hip's PreEmbed for the second prenet convolution)
+template <int NS, int RB, bool ASPLIT, int A_MODE, class Pre>
+__global__ void __launch_bounds__(1024 / RB) kernel_res_ln(LnArgs g, Pre pre) {
     extern __shared__ __attribute__((aligned(1024))) float ln_lds[];
     float* const lds = ln_lds;
     constexpr int NWAVE = 16 / RB;
@@ -54,22 +89,13 @@ __global__ void __launch_bounds__(1024 / RB) kernel_res_ln(LnArgs g) {
     const int nk = g.K / 32;
     const int m0 = blockIdx.x * LN_BM;
 
-    // the residual rows first: they are the oldest vector-memory operations of the wave, so the ring's vmcnt waits cover them
-    f32x4 res[RB][4];
-#pragma unroll
-    for (int b = 0; b < RB; ++b) {
-        const int row_m = m0 + 32 * (rg0 + b) + lr;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            res[b][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (row_m < g.M) res[b][q] = *(const f32x4*)(g.res + (int64_t)row_m * LN_N + 32 * cg + 8 * q + 4 * lh);
-        }
-    }
-    f32x4 bias4[4], gam4[4], bet4[4];   // (loaded now: one workgroup per CU, nothing would hide their latency in the epilogue)
+    // the epilogue's row operands first: they are the oldest vector-memory operations of the wave, so the ring's vmcnt waits cover them
+    typename Pre::State pst;
+    pre.template load<RB>(pst, g, m0, rg0, lr, cg, lh);
+    f32x4 gam4[4], bet4[4];   // (loaded now: one workgroup per CU, nothing would hide their latency in the epilogue)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int c0 = 32 * cg + 8 * q + 4 * lh;
-        bias4[q] = *(const f32x4*)(g.bias + c0);
         gam4[q] = *(const f32x4*)(g.gamma + c0);
         bet4[q] = *(const f32x4*)(g.beta + c0);
     }
@@ -78,6 +104,7 @@ __global__ void __launch_bounds__(1024 / RB) kernel_res_ln(LnArgs g) {
     // 8 waves: w, w + 8, ..., w + 32
     constexpr int MAXP = RB == 1 ? 3 : 5;
     const float* src[MAXP];
+    const float *src_m1 = nullptr, *src_p1 = nullptr;   // A_CONV3: taps 0 and 2 of this lane's A row (its piece is i = 0: wave < 8)
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
         const int piece = wave + NWAVE * i;
@@ -87,18 +114,37 @@ __global__ void __launch_bounds__(1024 / RB) kernel_res_ln(LnArgs g) {
             int m = m0 + row;
             m = m < g.M ? m : g.M - 1;
             src[i] = g.A + (int64_t)m * g.lda + slot * 4;
+            if constexpr (A_MODE == A_CONV3) {
+                const int f = m % g.Fr, sh = g.tap_shift;
+                const float* base = src[i];
+                const float* zp = g.zeros + slot * 4;
+                src_m1 = (f - 1 + sh >= 0 && f - 1 + sh < g.Fr) ? base + (int64_t)(sh - 1) * g.lda : zp;
+                src_p1 = (f + 1 + sh >= 0 && f + 1 + sh < g.Fr) ? base + (int64_t)(sh + 1) * g.lda : zp;
+                src[i] = (f + sh >= 0 && f + sh < g.Fr) ? base + (int64_t)sh * g.lda : zp;
+            }
         } else {
             const int n = row - LN_BM < LN_N ? row - LN_BM : LN_N - 1;
             src[i] = g.W + (int64_t)n * g.ldw + slot * 4;
         }
     }
+    static_assert(A_MODE == A_PLAIN || (A_MODE == A_CONV3 && RB == 2), "conv mode: eight waves, one A piece each");
     auto issue = [&](int kt) {
         float* const st = lds + (kt % NS) * LN_STAGE;
+        int tap = 1, koff = kt * 32;
+        if constexpr (A_MODE == A_CONV3) {
+            tap = koff / g.Cin;
+            koff -= tap * g.Cin;
+        }
 #pragma unroll
         for (int i = 0; i < MAXP; ++i)
-            if (RB == 2 || i < 2 || wave < 8)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + kt * 32),
+            if (RB == 2 || i < 2 || wave < 8) {
+                const float* p = src[i] + kt * 32;
+                if constexpr (A_MODE == A_CONV3) {
+                    if (i == 0) p = (tap == 0 ? src_m1 : tap == 1 ? src[0] : src_p1) + koff;
+                }
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                                  (__attribute__((address_space(3))) void*)(st + (wave + NWAVE * i) * 256), 16, 0, 0);
+            }
     };
 #pragma unroll
     for (int i = 0; i < NS - 1; ++i)
@@ -182,8 +228,9 @@ __global__ void __launch_bounds__(1024 / RB) kernel_res_ln(LnArgs g) {
         const int row = 32 * (rg0 + b) + lr;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[b][q][e] = res[b][q][e] + (acc[b][4 * q + e] + bias4[q][e]);
+            const int mr = m0 + row < g.M ? m0 + row : g.M - 1;
+            v[b][q] = pre.apply(pst, g, b, q, mr, 32 * cg + 8 * q + 4 * lh,
+                                f32x4{acc[b][4 * q], acc[b][4 * q + 1], acc[b][4 * q + 2], acc[b][4 * q + 3]});
             P1[row * PP + 8 * cg + 2 * q + lh] = (v[b][q][0] + v[b][q][1]) + (v[b][q][2] + v[b][q][3]);
             if (m0 + row < g.M) *(f32x4*)(g.X + (int64_t)(m0 + row) * LN_N + 32 * cg + 8 * q + 4 * lh) = v[b][q];
         }
@@ -253,19 +300,20 @@ inline bool res_ln_ok(const LnArgs& g) {
              (uintptr_t)g.beta | (uintptr_t)g.Y) % 16) == 0;
 }
 
-template <int RB, bool ASPLIT>
-inline hipError_t launch_res_ln_rb(hipStream_t st, const LnArgs& g) {
+template <int RB, bool ASPLIT, int A_MODE = A_PLAIN, class Pre = PreResidual>
+inline hipError_t launch_res_ln_rb(hipStream_t st, const LnArgs& g, const Pre& pre = Pre{}) {
     static std::atomic<uint64_t> done{0};   // devices on which the dynamic-LDS attribute has been set
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     const uint64_t bit = 1ull << (dev & 63);
+    auto kfn = kernel_res_ln<LN_NS, RB, ASPLIT, A_MODE, Pre>;
     if (!(done.load(std::memory_order_acquire) & bit)) {
-        e = hipFuncSetAttribute((const void*)kernel_res_ln<LN_NS, RB, ASPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LN_LDS_BYTES);
+        e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LN_LDS_BYTES);
         if (e != hipSuccess) return e;
         done.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((kernel_res_ln<LN_NS, RB, ASPLIT>), dim3((unsigned)((g.M + LN_BM - 1) / LN_BM)), dim3(1024 / RB), LN_LDS_BYTES, st, g);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)((g.M + LN_BM - 1) / LN_BM)), dim3(1024 / RB), LN_LDS_BYTES, st, g, pre);
     return hipSuccess;
 }
 // a_split: A is in the pre-split layout (else fp32 rows)

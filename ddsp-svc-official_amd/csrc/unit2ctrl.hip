@@ -395,6 +395,11 @@ struct EpiEmbed {
             *(f32x4*)(out + z * zstride + (int64_t)m * D + n) = v;
             return;
         }
+        *(f32x4*)(out + (int64_t)m * D + n) = embed4(m, n, v);
+    }
+    // bias + the side embeddings of row m for columns n .. n + 3 (the operation order of store4 above, which calls it)
+    __device__ __forceinline__ f32x4 embed4(int m, int n, f32x4 v) const {
+        typedef gemm::f32x4_u v4;
         v += *(const v4*)(bias + n);
         const float lf0 = logf(1.0f + __fdiv_rn(f0[m], 700.0f));
         const float ph = __fdiv_rn(phase[m], 3.14159274101257324f);
@@ -424,7 +429,18 @@ struct EpiEmbed {
                 __hip_atomic_store(err, DDSP_DEV_ERR_SPK_ID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
-        *(f32x4*)(out + (int64_t)m * D + n) = v;
+        return v;
+    }
+};
+
+// the same additions as the `Pre` of gemm::kernel_res_ln: second prenet convolution + embeddings + the first LayerNorm in one kernel
+struct PreEmbed {
+    EpiEmbed e;
+    struct State {};
+    template <int RB>
+    __device__ __forceinline__ void load(State&, const gemm::LnArgs&, int, int, int, int, int) const {}
+    __device__ __forceinline__ f32x4 apply(const State&, const gemm::LnArgs&, int, int, int m, int c0, f32x4 acc) const {
+        return e.embed4(m, c0, acc);
     }
 };
 
@@ -557,6 +573,16 @@ __global__ void __launch_bounds__(256) attn_denominator_kernel(const float* __re
     for (int j = lane; j < NF; j += 64) s = fmaf(q[j], k[j], s);
     s = wave_sum(s);
     if (lane == 0) dinv[r] = 1.0f / (s + 1e-8f);
+}
+
+// DDSP_CONV_LN=0: the second prenet convolution and the first LayerNorm as two launches at every size (measurement aid)
+static bool conv_ln_on() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("DDSP_CONV_LN");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
 }
 
 // DDSP_CAUSAL_CHUNKED=0: the causal network's inference attention on the sequential kernel below (measurement aid)
@@ -1895,7 +1921,19 @@ static int u2c_forward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w,
             pending = LnPending{bf.kpart, nullptr, x, 0};   // layer 0's LayerNorm sums the four partial products into x
         } else {
             EpiEmbed e{x, w.prenet_conv2_b, in.f0, in.phase, in.volume, w, in.spk_id, in.n_spk_id, in.mix, (int)Fr, dev_err, 0};
-            PROF(PF_U2C_GEMM_CONV3, 2.0 * M * D * 3 * D, 8.0 * M * D, (gemm::launch<true, true, gemm::A_CONV3>(st, g, 1, e)));
+            // large batches: the convolution, the embeddings AND the first block's LayerNorm in one kernel (gemm_ln.h with the
+            // 3-tap loader; same bits as the pair of launches)
+            gemm::LnArgs la = ln_args(g, x, x, w.prenet_conv2_b, w.layer[0].norm_w, w.layer[0].norm_b, bf.l[0].y);
+            la.Fr = (int)Fr;
+            la.Cin = D;
+            la.tap_shift = g.tap_shift;
+            la.zeros = zero_page;
+            if (conv_ln_on() && ln_fusable(g, la) && g.A_split && D + 32 <= DDSP_ZERO_FLOATS) {
+                PROF(PF_U2C_GEMM_CONV3, 2.0 * M * D * 3 * D, 12.0 * M * D,
+                     DDSP_HIP(ctx, (gemm::launch_res_ln_rb<2, true, gemm::A_CONV3, PreEmbed>(st, la, PreEmbed{e}))));
+                ln_done = true;
+            } else
+                PROF(PF_U2C_GEMM_CONV3, 2.0 * M * D * 3 * D, 8.0 * M * D, (gemm::launch<true, true, gemm::A_CONV3>(st, g, 1, e)));
         }
     }
     DDSP_LAUNCH_CHECK(ctx);
