@@ -2324,6 +2324,13 @@ static int wgrad_tile_choice() {
     }
     return v;
 }
+static bool attn_wgrad_on() {   // DDSP_ATTN_WGRAD=0: the K = frames product of the attention adjoint back on the register-staged fp32 kernel
+    static const bool v = [] {
+        const char* e = getenv("DDSP_ATTN_WGRAD");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
 static int layer_grads(ddsp_ctx* ctx, hipStream_t st, const float* dY, int64_t ldy, int O, const float* X, int64_t ldx, int C,
                        int taps, int Fr, int64_t M, float* wpart, float* cpart, float* xs, float* w_out, int64_t ldo,
                        float* b_out, int tap_shift = 0, WgDefer* defer = nullptr) {   // tap_shift: 0 centred taps, -1 causal taps (taps == 3 only)
@@ -2689,7 +2696,28 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
                 EpiRowOuter e{dQF, dD, b.ks, (int)Fr};
                 attn_k64(st, g, (int)(B * H), e);
             }
-            {   // d_ctx = q'^T d_num
+            if (ctx->math != DDSP_MATH_FP32 && attn_wgrad_on()) {   // d_ctx = q'^T d_num: the frames are the slow axis of both operands,
+                wgrad::Args g;                                        // the weight-gradient kernel with one problem per (utterance, head)
+                g.dY = b.qf;
+                g.ldy = (int64_t)H * LDF;
+                g.O = NF;
+                g.X = dB512;
+                g.ldx = INNER;
+                g.C = DH;
+                g.taps = 1;
+                g.tap_shift = 0;
+                g.Fr = (int)Fr;
+                g.M = Fr;
+                g.chunk = 32;
+                g.partial = dcx;
+                g.bias_partial = nullptr;
+                g.zdiv = H;
+                g.sY_hi = (int64_t)Fr * H * LDF;
+                g.sY_lo = LDF;
+                g.sX_hi = (int64_t)Fr * INNER;
+                g.sX_lo = DH;
+                wgrad::launch<1, 1>(st, g, (int)(B * H));   // (128-row tiles: no difference, 5.72 / 5.75 ms over two runs)
+            } else {   // d_ctx = q'^T d_num
                 gemm::Args g = gemm::make(b.qf, (int64_t)H * LDF, dB512, INNER, NF, DH, (int)Fr);
                 g.zdiv = H;
                 g.sA_hi = (int64_t)Fr * H * LDF;

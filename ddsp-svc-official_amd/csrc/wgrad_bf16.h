@@ -35,6 +35,10 @@ struct Args {
     int chunk;   // rows per split, a multiple of 32
     float* partial;        // [splits][O][taps * C]
     float* bias_partial;   // [splits][O] or null
+    // batched mode (zdiv > 0): blockIdx.z is an independent problem (hi, lo) = (z / zdiv, z % zdiv) over all M rows instead of a
+    // split of the rows; operand bases move by the strides below and `partial` holds one [O][C] product per problem
+    int zdiv = 0;
+    int64_t sY_hi = 0, sY_lo = 0, sX_hi = 0, sX_lo = 0;
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -52,8 +56,13 @@ __global__ void __launch_bounds__(256) kernel(Args g) {
     const int tap = n0 / g.C, c0 = n0 - tap * g.C;
     const int shift = tap - (g.taps - 1) / 2 + g.tap_shift;
     const int z = blockIdx.z;
-    const int64_t kbeg = (int64_t)z * g.chunk;
-    const int64_t kend = kbeg + g.chunk < g.M ? kbeg + g.chunk : g.M;
+    if (g.zdiv > 0) {
+        const int zh = z / g.zdiv, zl = z - zh * g.zdiv;
+        g.dY += zh * g.sY_hi + zl * g.sY_lo;
+        g.X += zh * g.sX_hi + zl * g.sX_lo;
+    }
+    const int64_t kbeg = g.zdiv > 0 ? 0 : (int64_t)z * g.chunk;
+    const int64_t kend = g.zdiv > 0 ? g.M : (kbeg + g.chunk < g.M ? kbeg + g.chunk : g.M);
     const int nk = (int)((kend - kbeg + 31) / 32);
     const bool want_bias = g.bias_partial != nullptr && blockIdx.x == 0;
     const bool a_cols_full = o0 + BM <= g.O, b_cols_full = c0 + BN <= g.C;
@@ -201,9 +210,9 @@ inline int chunk_for(int64_t M, int want) {
 inline int splits_for(int64_t M, int chunk) { return (int)((M + chunk - 1) / chunk); }
 
 template <int TM, int TN>
-inline void launch(hipStream_t st, const Args& g) {
+inline void launch(hipStream_t st, const Args& g, int batch = 0) {
     const int N = g.taps * g.C;
-    dim3 grid((N + 64 * TN - 1) / (64 * TN), (g.O + 64 * TM - 1) / (64 * TM), splits_for(g.M, g.chunk));
+    dim3 grid((N + 64 * TN - 1) / (64 * TN), (g.O + 64 * TM - 1) / (64 * TM), batch > 0 ? batch : splits_for(g.M, g.chunk));
     hipLaunchKernelGGL((kernel<TM, TN>), grid, dim3(256), 0, st, g);
 }
 
