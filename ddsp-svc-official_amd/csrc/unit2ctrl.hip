@@ -2710,7 +2710,12 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
                 g.M = Fr;
                 g.chunk = 32;
                 g.partial = dcx;
-                g.bias_partial = nullptr;
+                g.bias_partial = dks;          // d_ks = q'^T d_D rides in the staging threads (was weighted_key_sum_kernel)
+                g.ldb = LDF;
+                g.bias_w = dD;
+                g.ldw = H;
+                g.sW_hi = (int64_t)Fr * H;
+                g.sW_lo = 1;
                 g.zdiv = H;
                 g.sY_hi = (int64_t)Fr * H * LDF;
                 g.sY_lo = LDF;
@@ -2727,7 +2732,8 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
                 gemm::EpiStore e{dcx, DH, nullptr, 1, (int64_t)NF * DH, 0};
                 gemm::launch_tile<64, 64, false, false, gemm::A_PLAIN>(st, g, (int)(B * H), e);
             }
-            hipLaunchKernelGGL(weighted_key_sum_kernel, dim3((unsigned)(B * H)), dim3(KS_T * 8), 0, st, b.qf, dD, (int)Fr, dks);
+            if (!(ctx->math != DDSP_MATH_FP32 && attn_wgrad_on()))
+                hipLaunchKernelGGL(weighted_key_sum_kernel, dim3((unsigned)(B * H)), dim3(KS_T * 8), 0, st, b.qf, dD, (int)Fr, dks);
             {   // d_k' = v d_ctx^T + d_ks^T
                 gemm::Args g = gemm::make(b.v, INNER, dcx, DH, (int)Fr, NF, DH);
                 g.zdiv = H;

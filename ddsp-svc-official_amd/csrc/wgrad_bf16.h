@@ -39,6 +39,10 @@ struct Args {
     // split of the rows; operand bases move by the strides below and `partial` holds one [O][C] product per problem
     int zdiv = 0;
     int64_t sY_hi = 0, sY_lo = 0, sX_hi = 0, sX_lo = 0;
+    // weighted column sums (batched mode): bias_partial[z * ldb + o] = sum_m dY[m][o] * bias_w[m * ldw] instead of the plain sums
+    const float* bias_w = nullptr;
+    int64_t ldw = 0, sW_hi = 0, sW_lo = 0;
+    int64_t ldb = 0;   // row stride of bias_partial (0: O)
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -60,6 +64,7 @@ __global__ void __launch_bounds__(256) kernel(Args g) {
         const int zh = z / g.zdiv, zl = z - zh * g.zdiv;
         g.dY += zh * g.sY_hi + zl * g.sY_lo;
         g.X += zh * g.sX_hi + zl * g.sX_lo;
+        if (g.bias_w) g.bias_w += zh * g.sW_hi + zl * g.sW_lo;
     }
     const int64_t kbeg = g.zdiv > 0 ? 0 : (int64_t)z * g.chunk;
     const int64_t kend = g.zdiv > 0 ? g.M : (kbeg + g.chunk < g.M ? kbeg + g.chunk : g.M);
@@ -109,7 +114,7 @@ __global__ void __launch_bounds__(256) kernel(Args g) {
             }
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, int kt) {
         ddsp_u32x4* as = lds + buf * STAGE;
         ddsp_u32x4* bs = as + 8 * BM;
 #pragma unroll
@@ -119,8 +124,17 @@ __global__ void __launch_bounds__(256) kernel(Args g) {
             ddsp_split8(ra[i], hi, lo);
             as[(2 * kg) * BM + o] = hi;
             as[(2 * kg + 1) * BM + o] = lo;
-            if (want_bias)
-                bsum[i] += ((ra[i][0] + ra[i][1]) + (ra[i][2] + ra[i][3])) + ((ra[i][4] + ra[i][5]) + (ra[i][6] + ra[i][7]));
+            if (want_bias) {
+                if (g.bias_w) {
+                    const int64_t m0 = kbeg + (int64_t)kt * 32 + kg * 8;
+                    float wt[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) wt[j] = m0 + j < kend ? g.bias_w[(m0 + j) * g.ldw] : 0.f;
+                    bsum[i] += ((ra[i][0] * wt[0] + ra[i][1] * wt[1]) + (ra[i][2] * wt[2] + ra[i][3] * wt[3])) +
+                               ((ra[i][4] * wt[4] + ra[i][5] * wt[5]) + (ra[i][6] * wt[6] + ra[i][7] * wt[7]));
+                } else
+                    bsum[i] += ((ra[i][0] + ra[i][1]) + (ra[i][2] + ra[i][3])) + ((ra[i][4] + ra[i][5]) + (ra[i][6] + ra[i][7]));
+            }
         }
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
@@ -142,7 +156,7 @@ __global__ void __launch_bounds__(256) kernel(Args g) {
 
     if (nk > 0) {
         load_tiles(0);
-        store_tiles(0);
+        store_tiles(0, 0);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -173,7 +187,7 @@ __global__ void __launch_bounds__(256) kernel(Args g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        if (kt + 1 < nk) store_tiles(buf ^ 1, kt + 1);
         __syncthreads();
     }
 
@@ -197,7 +211,7 @@ __global__ void __launch_bounds__(256) kernel(Args g) {
         for (int i = 0; i < TM; ++i) red[tid + 256 * i] = bsum[i];   // index = kg * BM + o
         __syncthreads();
         if (tid < BM && o0 + tid < g.O)
-            g.bias_partial[(int64_t)z * g.O + o0 + tid] = (red[tid] + red[BM + tid]) + (red[2 * BM + tid] + red[3 * BM + tid]);
+            g.bias_partial[(int64_t)z * (g.ldb ? g.ldb : g.O) + o0 + tid] = (red[tid] + red[BM + tid]) + (red[2 * BM + tid] + red[3 * BM + tid]);
     }
 }
 
