@@ -1377,6 +1377,176 @@ __global__ void __launch_bounds__(256) feature_map_bwd_kernel(const float* __res
     if (lane == 0) coef[r] = -(dn * dn) * t;
 }
 
+// ---- fused adjoint of one feature-map side of the attention (round 3, split-bf16 arithmetic) ----
+// What five launches did through HBM (EpiRowOuter product -> feature_map_bwd_kernel -> product with the projection), one wavefront
+// does in registers for 16 frames of one (utterance, head):
+//   S[j][n]  = sum_k mat[j][k] rows[n][k] + rowscale[n] colvec[j]        (j: 266 features, k: 64; 17 x 2 x 3 MFMA 16x16x32)
+//   dd       = S * E(feat);  t[n] = sum_j dd;  d_feat = dn (dd - [j == argmax_j feat] t)   (query side; key side: no arg-max term)
+//   out[n][d] = sum_j d_feat[j][n] P[j][d] - dn^2 t[n] src[n][d]         (9 x 4 x 3 MFMA)
+// The first product is taken transposed (features on the M axis), so a lane owns one frame and 4 consecutive features per
+// 16-feature block: the sums over features are in-lane plus two cross-lane steps, and those registers ARE the K operand of the
+// second product when the projection is stored in the matching slot order (feat_proj_prep_kernel: slot (g, s) of k-step ks
+// holds feature 32 ks + 4 g + s for s < 4 and 32 ks + 16 + 4 g + s - 4 above).  A linear map of a gradient: 3 split products.
+constexpr int FB_KS = 9;                              // k-steps of the second product (266 features padded to 288)
+constexpr int FB_PT_VEC = FB_KS * 4 * 64 * 2;         // 16-byte vectors of one prepared projection
+__global__ void __launch_bounds__(256) feat_proj_prep_kernel(const float* __restrict__ P, ddsp_u32x4* __restrict__ dst) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;   // (ks, blk, lane)
+    if (idx >= FB_KS * 4 * 64) return;
+    const int lane = idx & 63, blk = (idx >> 6) & 3, ks = idx >> 8;
+    const int d = 16 * blk + (lane & 15), g = lane >> 4;
+    float x[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int j = 32 * ks + (s < 4 ? 4 * g + s : 16 + 4 * g + s - 4);
+        x[s] = j < NF ? P[(int64_t)j * DH + d] : 0.f;
+    }
+    ddsp_u32x4 hi, lo;
+    ddsp_split8(x, hi, lo);
+    dst[2 * idx] = hi;
+    dst[2 * idx + 1] = lo;
+}
+struct FeatBwdArgs {
+    const float* rows;       // query side: d_num (M, 512);            key side: v (M, 512)
+    const float* mat;        // query side: ctx (B*H, NF, DH);          key side: d_ctx
+    const float* rowscale;   // query side: d_D (M8);                   key side: null (1)
+    const float* colvec;     // query side: ks (B*H, LDF);              key side: d_ks
+    const float* feat;       // q' / k' (M8, LDF)
+    const ddsp_u32x4* pt;    // prepared projection
+    const float* src;        // q / k (M, 512)
+    float* out;              // d_q / d_k (M, 512)
+    int Fr;
+};
+typedef __bf16 fb_bf16x8 __attribute__((ext_vector_type(8)));
+template <bool QUERY>
+__global__ void __launch_bounds__(256) attn_feat_bwd_kernel(FeatBwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int f0 = (blockIdx.x * 4 + wave) * 16;
+    if (f0 >= a.Fr) return;   // (no barrier in this kernel)
+    const bool live = f0 + n < a.Fr;
+    const int f = live ? f0 + n : a.Fr - 1;
+    const int64_t row = ((int64_t)b * a.Fr + f) * H + h;
+    const float dn = 0.35355339059327373f, ratio = 0.06131393394849658f;
+
+    fb_bf16x8 xh[2], xl[2];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        const float* p = a.rows + row * DH + 32 * kh + 8 * g;
+        const f32x4 u = *(const f32x4*)p, v = *(const f32x4*)(p + 4);
+        const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+        ddsp_u32x4 hi, lo;
+        ddsp_split8(x, hi, lo);
+        xh[kh] = __builtin_bit_cast(fb_bf16x8, hi);
+        xl[kh] = __builtin_bit_cast(fb_bf16x8, lo);
+    }
+    const float* mat = a.mat + (int64_t)bh * NF * DH;
+    f32x4 S[17];
+#pragma unroll
+    for (int blk = 0; blk < 17; ++blk) {
+        const int j = 16 * blk + n;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            f32x4 u = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
+            if (j < NF) {
+                const float* p = mat + (int64_t)j * DH + 32 * kh + 8 * g;
+                u = *(const f32x4*)p;
+                v = *(const f32x4*)(p + 4);
+            }
+            const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+            ddsp_u32x4 hi, lo;
+            ddsp_split8(x, hi, lo);
+            const fb_bf16x8 mh = __builtin_bit_cast(fb_bf16x8, hi), ml = __builtin_bit_cast(fb_bf16x8, lo);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ml, xh[kh], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mh, xl[kh], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mh, xh[kh], acc, 0, 0, 0);
+        }
+        S[blk] = acc;
+    }
+    // feature-map adjoint on the registers (feature of S[blk][r]: 16 blk + 4 g + r)
+    const float rs = QUERY ? a.rowscale[row] : 1.0f;
+    const float* fr = a.feat + row * LDF;
+    const float* cv = a.colvec + (int64_t)bh * LDF;
+    float t = 0.f, best = -3.0e38f;
+    int arg = 0x7fffffff;
+#pragma unroll
+    for (int blk = 0; blk < 17; ++blk) {
+        const int j0 = 16 * blk + 4 * g;
+        f32x4 fv = {0.f, 0.f, 0.f, 0.f}, c4 = {0.f, 0.f, 0.f, 0.f};
+        if (j0 < NF) {   // (rows are LDF = 268 floats: the last group that holds a feature is 264..267)
+            fv = *(const f32x4*)(fr + j0);
+            c4 = *(const f32x4*)(cv + j0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool valid = j0 + r < NF;
+            const float E = QUERY ? fv[r] - ratio * 1e-4f : fv[r];
+            const float dd = valid ? fmaf(rs, c4[r], S[blk][r]) * E : 0.f;
+            S[blk][r] = dd;
+            t += dd;
+            if (QUERY && valid && fv[r] > best) {
+                best = fv[r];
+                arg = j0 + r;
+            }
+        }
+    }
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    if (QUERY) {   // first index of the row maximum, like feature_map_bwd_kernel
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oa = __shfl_xor(arg, o, 64);
+            if (ob > best || (ob == best && oa < arg)) {
+                best = ob;
+                arg = oa;
+            }
+        }
+    }
+    f32x4 o4[4];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) o4[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < FB_KS; ++ks) {
+        float y[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v0 = S[2 * ks][r];
+            if (QUERY && 32 * ks + 4 * g + r == arg) v0 -= t;
+            y[r] = dn * v0;
+            float v1 = 0.f;
+            if (2 * ks + 1 < 17) {
+                v1 = S[2 * ks + 1 < 17 ? 2 * ks + 1 : 16][r];
+                if (QUERY && 32 * ks + 16 + 4 * g + r == arg) v1 -= t;
+            }
+            y[4 + r] = dn * v1;
+        }
+        ddsp_u32x4 hi, lo;
+        ddsp_split8(y, hi, lo);
+        const fb_bf16x8 yh = __builtin_bit_cast(fb_bf16x8, hi), yl = __builtin_bit_cast(fb_bf16x8, lo);
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            const ddsp_u32x4* p = a.pt + ((ks * 4 + blk) * 64 + lane) * 2;
+            const fb_bf16x8 ph = __builtin_bit_cast(fb_bf16x8, p[0]), pl = __builtin_bit_cast(fb_bf16x8, p[1]);
+            o4[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, yh, o4[blk], 0, 0, 0);
+            o4[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, yl, o4[blk], 0, 0, 0);
+            o4[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, yh, o4[blk], 0, 0, 0);
+        }
+    }
+    if (!live) return;
+    const float coef = -(dn * dn) * t;
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+        const int64_t off = row * DH + 16 * blk + 4 * g;
+        const f32x4 s4 = *(const f32x4*)(a.src + off);
+        f32x4 r4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) r4[r] = fmaf(coef, s4[r], o4[blk][r]);
+        *(f32x4*)(a.out + off) = r4;
+    }
+}
+
 struct EpiRowOuter {  // out[(b*Fr+m)*8+h][j] = acc + rowscale[row] * colvec[(b*8+h)][j]   (z = b*8+h); rowscale null -> 1
     float* out;
     const float* rowscale;
@@ -2324,6 +2494,13 @@ static int wgrad_tile_choice() {
     }
     return v;
 }
+static bool attn_feat_fused_on() {   // DDSP_ATTN_FEAT_FUSED=0: the feature-map adjoints back on the five-launch chain through HBM
+    static const bool v = [] {
+        const char* e = getenv("DDSP_ATTN_FEAT_FUSED");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
 static bool attn_wgrad_on() {   // DDSP_ATTN_WGRAD=0: the K = frames product of the attention adjoint back on the register-staged fp32 kernel
     static const bool v = [] {
         const char* e = getenv("DDSP_ATTN_WGRAD");
@@ -2536,7 +2713,7 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
     // ---- arena: kept forward activations + backward temporaries ----
     U2CBufs bf;
     float *ctrl = nullptr, *dX, *dA, *dB512, *dC512, *dV512, *dG1, *dQF, *dKF, *dcx, *dks, *dD, *coefq, *coefk, *gx, *wpart, *cpart,
-        *dWh, *pk, *xs, *dwpart, *gbst, *w2t, *wts, *wpool;
+        *dWh, *pk, *xs, *dwpart, *gbst, *w2t, *wts, *wpool, *ptp;
     // partial sums of the 18 Linear layers of the blocks, reduced by one launch at the end (WgDefer): 17 splits at most
     const size_t wpool_floats = (size_t)(WG_SPLITS + 1) * 3 * ((size_t)2 * D * INNER + (size_t)2 * INNER * D + (size_t)3 * INNER * D + 2 * D + 2 * INNER + 3 * INNER + 1024);
     auto plan_bwd = [&](Arena& a) {
@@ -2569,6 +2746,7 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
         w2t = a.get((size_t)D * 3 * D);
         wts = a.get((size_t)NO * D + 3 * ((size_t)2 * D * INNER + (size_t)2 * INNER * D + (size_t)3 * INNER * D));
         wpool = a.get(wpool_floats);
+        ptp = a.get((size_t)3 * FB_PT_VEC * 4);   // prepared projections of attn_feat_bwd_kernel
     };
     if (keep) {
         Arena k{ctx, false, 0, 0, (char*)keep, keep_bytes};
@@ -2619,6 +2797,11 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
         static_assert(TS_MAX >= 19, "table too small");
         hipLaunchKernelGGL(transpose_split_kernel, dim3(64, n), dim3(256), 0, st, ts);
     }
+    const bool feat_fused = ctx->math != DDSP_MATH_FP32 && !w.causal && attn_feat_fused_on();
+    if (feat_fused)
+        for (int l = 0; l < 3; ++l)
+            hipLaunchKernelGGL(feat_proj_prep_kernel, dim3((FB_KS * 4 * 64 + 255) / 256), dim3(256), 0, st, w.layer[l].proj,
+                               reinterpret_cast<ddsp_u32x4*>(ptp) + (size_t)l * FB_PT_VEC);
     WgDefer df{};
     df.pool = wpool;
     df.cap = wpool_floats;
@@ -2686,7 +2869,7 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
                                dV512);
         } else {
             hipLaunchKernelGGL(attn_out_bwd_kernel, dim3(rows8_g), dim3(256), 0, st, dB512, b.attn, b.dinv, M8, dD);  // d_num, d_D
-            {   // d_q' = d_num ctx^T + d_D ks^T
+            if (!feat_fused) {   // d_q' = d_num ctx^T + d_D ks^T
                 gemm::Args g = gemm::make(dB512, INNER, b.cx, DH, (int)Fr, NF, DH);
                 g.zdiv = H;
                 g.sA_hi = (int64_t)Fr * INNER;
@@ -2734,7 +2917,14 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
             }
             if (!(ctx->math != DDSP_MATH_FP32 && attn_wgrad_on()))
                 hipLaunchKernelGGL(weighted_key_sum_kernel, dim3((unsigned)(B * H)), dim3(KS_T * 8), 0, st, b.qf, dD, (int)Fr, dks);
-            {   // d_k' = v d_ctx^T + d_ks^T
+            if (feat_fused) {   // d_q (in place of d_num, which the d_ctx launch above has consumed) and d_k: attn_feat_bwd_kernel
+                const dim3 fgrid((unsigned)((Fr + 63) / 64), (unsigned)(B * H));
+                const ddsp_u32x4* pt = reinterpret_cast<const ddsp_u32x4*>(ptp) + (size_t)l * FB_PT_VEC;
+                FeatBwdArgs fq{dB512, b.cx, dD, b.ks, b.qf, pt, b.q, dB512, (int)Fr};
+                hipLaunchKernelGGL(attn_feat_bwd_kernel<true>, fgrid, dim3(256), 0, st, fq);
+                FeatBwdArgs fk{b.v, dcx, nullptr, dks, b.kf, pt, b.k, dC512, (int)Fr};
+                hipLaunchKernelGGL(attn_feat_bwd_kernel<false>, fgrid, dim3(256), 0, st, fk);
+            } else {   // d_k' = v d_ctx^T + d_ks^T
                 gemm::Args g = gemm::make(b.v, INNER, dcx, DH, (int)Fr, NF, DH);
                 g.zdiv = H;
                 g.sA_hi = (int64_t)Fr * INNER;
@@ -2755,9 +2945,11 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
                 gemm::launch_tile<64, 64, true, false, gemm::A_PLAIN>(st, g, (int)(B * H), e);
             }
         }
+        if (!(feat_fused && !w.causal)) {
         hipLaunchKernelGGL(feature_map_bwd_kernel<true>, dim3(rows8_g), dim3(256), 0, st, b.qf, dQF, M8, coefq);
         hipLaunchKernelGGL(feature_map_bwd_kernel<false>, dim3(rows8_g), dim3(256), 0, st, b.kf, dKF, M8, coefk);
-        {   // d_q = d_raw_q P + coef_q q   (rows = (frame, head), 64 columns == the (M, 512) layout of q)
+        }
+        if (!(feat_fused && !w.causal)) {   // d_q = d_raw_q P + coef_q q   (rows = (frame, head), 64 columns == the (M, 512) layout of q)
             gemm::Args g = gemm::make(dQF, LDF, L.proj, DH, (int)M8, DH, NF);
             EpiAxpyRow e{dB512, coefq, b.q, DH};
             gemm::launch<true, false, gemm::A_PLAIN>(st, g, 1, e);
