@@ -1402,8 +1402,8 @@ __global__ void __launch_bounds__(256) feat_proj_prep_kernel(const float* __rest
     }
     ddsp_u32x4 hi, lo;
     ddsp_split8(x, hi, lo);
-    dst[2 * idx] = hi;
-    dst[2 * idx + 1] = lo;
+    dst[(idx >> 6) * 128 + lane] = hi;   // planar: 64 lanes of hi, then 64 lanes of lo (conflict-free 16-byte LDS reads)
+    dst[(idx >> 6) * 128 + 64 + lane] = lo;
 }
 struct FeatBwdArgs {
     const float* rows;       // query side: d_num (M, 512);            key side: v (M, 512)
@@ -1417,18 +1417,42 @@ struct FeatBwdArgs {
     int Fr;
 };
 typedef __bf16 fb_bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int FB_WAVES = 8;                                 // 16-frame tiles per workgroup (one (utterance, head) per blockIdx.y)
+constexpr int FB_MAT_VEC = 17 * 2 * 64 * 2;                 // 16-byte vectors of the staged, split `mat` operand
+constexpr int FB_LDS_BYTES = (FB_MAT_VEC + FB_PT_VEC) * 16; // 143 360
 template <bool QUERY>
-__global__ void __launch_bounds__(256) attn_feat_bwd_kernel(FeatBwdArgs a) {
+__global__ void __launch_bounds__(64 * FB_WAVES) attn_feat_bwd_kernel(FeatBwdArgs a) {
+    extern __shared__ ddsp_u32x4 fb_lds[];
+    ddsp_u32x4* const mats = fb_lds;                  // [blk 17][k-half 2][hi | lo][lane 64]: the A operand of the first product
+    ddsp_u32x4* const pts = fb_lds + FB_MAT_VEC;      // the prepared projection, as stored
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4;
     const int bh = blockIdx.y, b = bh / H, h = bh % H;
-    const int f0 = (blockIdx.x * 4 + wave) * 16;
-    if (f0 >= a.Fr) return;   // (no barrier in this kernel)
+    const int f0 = (blockIdx.x * FB_WAVES + wave) * 16;
     const bool live = f0 + n < a.Fr;
     const int f = live ? f0 + n : a.Fr - 1;
     const int64_t row = ((int64_t)b * a.Fr + f) * H + h;
     const float dn = 0.35355339059327373f, ratio = 0.06131393394849658f;
 
+    {   // stage: every thread splits its share of the (266, 64) matrix once for the 8 wavefronts; the projection is copied
+        const float* mat = a.mat + (int64_t)bh * NF * DH;
+        for (int e = threadIdx.x; e < 17 * 2 * 64; e += 64 * FB_WAVES) {
+            const int el = e & 63, kh = (e >> 6) & 1, blk = e >> 7;
+            const int j = 16 * blk + (el & 15);
+            f32x4 u = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
+            if (j < NF) {
+                const float* p = mat + (int64_t)j * DH + 32 * kh + 8 * (el >> 4);
+                u = *(const f32x4*)p;
+                v = *(const f32x4*)(p + 4);
+            }
+            const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+            ddsp_u32x4 hi, lo;
+            ddsp_split8(x, hi, lo);
+            mats[(e >> 6) * 128 + el] = hi;
+            mats[(e >> 6) * 128 + 64 + el] = lo;
+        }
+        for (int e = threadIdx.x; e < FB_PT_VEC; e += 64 * FB_WAVES) pts[e] = a.pt[e];
+    }
     fb_bf16x8 xh[2], xl[2];
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
@@ -1440,24 +1464,16 @@ __global__ void __launch_bounds__(256) attn_feat_bwd_kernel(FeatBwdArgs a) {
         xh[kh] = __builtin_bit_cast(fb_bf16x8, hi);
         xl[kh] = __builtin_bit_cast(fb_bf16x8, lo);
     }
-    const float* mat = a.mat + (int64_t)bh * NF * DH;
+    __syncthreads();
+    if (f0 >= a.Fr) return;   // (the only barrier is behind us)
     f32x4 S[17];
 #pragma unroll
     for (int blk = 0; blk < 17; ++blk) {
-        const int j = 16 * blk + n;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
-            f32x4 u = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
-            if (j < NF) {
-                const float* p = mat + (int64_t)j * DH + 32 * kh + 8 * g;
-                u = *(const f32x4*)p;
-                v = *(const f32x4*)(p + 4);
-            }
-            const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
-            ddsp_u32x4 hi, lo;
-            ddsp_split8(x, hi, lo);
-            const fb_bf16x8 mh = __builtin_bit_cast(fb_bf16x8, hi), ml = __builtin_bit_cast(fb_bf16x8, lo);
+            const ddsp_u32x4* p = mats + (blk * 2 + kh) * 128 + lane;
+            const fb_bf16x8 mh = __builtin_bit_cast(fb_bf16x8, p[0]), ml = __builtin_bit_cast(fb_bf16x8, p[64]);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ml, xh[kh], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mh, xl[kh], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mh, xh[kh], acc, 0, 0, 0);
@@ -1527,8 +1543,8 @@ __global__ void __launch_bounds__(256) attn_feat_bwd_kernel(FeatBwdArgs a) {
         const fb_bf16x8 yh = __builtin_bit_cast(fb_bf16x8, hi), yl = __builtin_bit_cast(fb_bf16x8, lo);
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk) {
-            const ddsp_u32x4* p = a.pt + ((ks * 4 + blk) * 64 + lane) * 2;
-            const fb_bf16x8 ph = __builtin_bit_cast(fb_bf16x8, p[0]), pl = __builtin_bit_cast(fb_bf16x8, p[1]);
+            const ddsp_u32x4* p = pts + (ks * 4 + blk) * 128 + lane;
+            const fb_bf16x8 ph = __builtin_bit_cast(fb_bf16x8, p[0]), pl = __builtin_bit_cast(fb_bf16x8, p[64]);
             o4[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, yh, o4[blk], 0, 0, 0);
             o4[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, yl, o4[blk], 0, 0, 0);
             o4[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, yh, o4[blk], 0, 0, 0);
@@ -2918,12 +2934,14 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
             if (!(ctx->math != DDSP_MATH_FP32 && attn_wgrad_on()))
                 hipLaunchKernelGGL(weighted_key_sum_kernel, dim3((unsigned)(B * H)), dim3(KS_T * 8), 0, st, b.qf, dD, (int)Fr, dks);
             if (feat_fused) {   // d_q (in place of d_num, which the d_ctx launch above has consumed) and d_k: attn_feat_bwd_kernel
-                const dim3 fgrid((unsigned)((Fr + 63) / 64), (unsigned)(B * H));
+                const dim3 fgrid((unsigned)((Fr + 16 * FB_WAVES - 1) / (16 * FB_WAVES)), (unsigned)(B * H));
+                DDSP_ONCE_PER_DEVICE(ctx, DDSP_HIP(ctx, hipFuncSetAttribute((const void*)attn_feat_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES));
+                                     DDSP_HIP(ctx, hipFuncSetAttribute((const void*)attn_feat_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES)));
                 const ddsp_u32x4* pt = reinterpret_cast<const ddsp_u32x4*>(ptp) + (size_t)l * FB_PT_VEC;
                 FeatBwdArgs fq{dB512, b.cx, dD, b.ks, b.qf, pt, b.q, dB512, (int)Fr};
-                hipLaunchKernelGGL(attn_feat_bwd_kernel<true>, fgrid, dim3(256), 0, st, fq);
+                hipLaunchKernelGGL(attn_feat_bwd_kernel<true>, fgrid, dim3(64 * FB_WAVES), FB_LDS_BYTES, st, fq);
                 FeatBwdArgs fk{b.v, dcx, nullptr, dks, b.kf, pt, b.k, dC512, (int)Fr};
-                hipLaunchKernelGGL(attn_feat_bwd_kernel<false>, fgrid, dim3(256), 0, st, fk);
+                hipLaunchKernelGGL(attn_feat_bwd_kernel<false>, fgrid, dim3(64 * FB_WAVES), FB_LDS_BYTES, st, fk);
             } else {   // d_k' = v d_ctx^T + d_ks^T
                 gemm::Args g = gemm::make(b.v, INNER, dcx, DH, (int)Fr, NF, DH);
                 g.zdiv = H;
