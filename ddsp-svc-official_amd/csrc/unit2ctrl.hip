@@ -1415,43 +1415,62 @@ struct FeatBwdArgs {
     const float* src;        // q / k (M, 512)
     float* out;              // d_q / d_k (M, 512)
     int Fr;
+    int ablate;              // timing experiments only (DDSP_FEAT_ABLATE): 1 no feature-row loads, 2 no first product, 4 no second product, 8 no staging
 };
 typedef __bf16 fb_bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int FB_WAVES = 8;                                 // 16-frame tiles per workgroup (one (utterance, head) per blockIdx.y)
+constexpr int FB_WAVES = 4;                                 // 16-frame tiles per workgroup
 constexpr int FB_MAT_VEC = 17 * 2 * 64 * 2;                 // 16-byte vectors of the staged, split `mat` operand
-constexpr int FB_LDS_BYTES = (FB_MAT_VEC + FB_PT_VEC) * 16; // 143 360
+// LDS: one region holds the split matrix during the first product and the prepared projection during the second (74 816 bytes:
+// two workgroups per CU - at ~250 VGPRs a SIMD holds two wavefronts, one of each), then the column vector
+constexpr int FB_REGION_VEC = FB_PT_VEC > FB_MAT_VEC ? FB_PT_VEC : FB_MAT_VEC;
+constexpr int FB_LDS_BYTES = (FB_REGION_VEC + 68) * 16;
 template <bool QUERY>
-__global__ void __launch_bounds__(64 * FB_WAVES) attn_feat_bwd_kernel(FeatBwdArgs a) {
+__global__ void __launch_bounds__(64 * FB_WAVES, 2) attn_feat_bwd_kernel(FeatBwdArgs a) {
     extern __shared__ ddsp_u32x4 fb_lds[];
     ddsp_u32x4* const mats = fb_lds;                  // [blk 17][k-half 2][hi | lo][lane 64]: the A operand of the first product
-    ddsp_u32x4* const pts = fb_lds + FB_MAT_VEC;      // the prepared projection, as stored
+    ddsp_u32x4* const pts = fb_lds;                   // later: the prepared projection, as stored
+    f32x4* const cvs = reinterpret_cast<f32x4*>(fb_lds + FB_REGION_VEC);   // colvec (LDF = 268 floats = 67 vectors)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4;
-    const int bh = blockIdx.y, b = bh / H, h = bh % H;
-    const int f0 = (blockIdx.x * FB_WAVES + wave) * 16;
+    // blockIdx.x = (utterance, head), blockIdx.y = 64-frame block: workgroups are dealt to the XCDs round-robin in x-major
+    // order, so the full blocks come first and the short tail blocks (172 frames: 4 + 4 + 3 tiles) last
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int f0 = (blockIdx.y * FB_WAVES + wave) * 16;
+    const bool active = f0 < a.Fr;                    // (idle wavefronts of a tail block still stage and meet the barriers)
     const bool live = f0 + n < a.Fr;
     const int f = live ? f0 + n : a.Fr - 1;
     const int64_t row = ((int64_t)b * a.Fr + f) * H + h;
     const float dn = 0.35355339059327373f, ratio = 0.06131393394849658f;
 
-    {   // stage: every thread splits its share of the (266, 64) matrix once for the 8 wavefronts; the projection is copied
+    {   // stage: every thread splits its share of the (266, 64) matrix once for the workgroup
         const float* mat = a.mat + (int64_t)bh * NF * DH;
-        for (int e = threadIdx.x; e < 17 * 2 * 64; e += 64 * FB_WAVES) {
+        constexpr int NT = 64 * FB_WAVES, MAT_IT = (17 * 2 * 64 + NT - 1) / NT;
+        f32x4 mu[MAT_IT], mv[MAT_IT];
+#pragma unroll
+        for (int i = 0; i < MAT_IT; ++i) {   // all loads of the stage are issued before the first use
+            const int e = threadIdx.x + i * NT;
             const int el = e & 63, kh = (e >> 6) & 1, blk = e >> 7;
             const int j = 16 * blk + (el & 15);
-            f32x4 u = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
-            if (j < NF) {
+            mu[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (e < 17 * 2 * 64 && j < NF && !(a.ablate & 8)) {
                 const float* p = mat + (int64_t)j * DH + 32 * kh + 8 * (el >> 4);
-                u = *(const f32x4*)p;
-                v = *(const f32x4*)(p + 4);
+                mu[i] = *(const f32x4*)p;
+                mv[i] = *(const f32x4*)(p + 4);
             }
-            const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
-            ddsp_u32x4 hi, lo;
-            ddsp_split8(x, hi, lo);
-            mats[(e >> 6) * 128 + el] = hi;
-            mats[(e >> 6) * 128 + 64 + el] = lo;
         }
-        for (int e = threadIdx.x; e < FB_PT_VEC; e += 64 * FB_WAVES) pts[e] = a.pt[e];
+#pragma unroll
+        for (int i = 0; i < MAT_IT; ++i) {
+            const int e = threadIdx.x + i * NT;
+            if (e < 17 * 2 * 64) {
+                const float x[8] = {mu[i][0], mu[i][1], mu[i][2], mu[i][3], mv[i][0], mv[i][1], mv[i][2], mv[i][3]};
+                ddsp_u32x4 hi, lo;
+                ddsp_split8(x, hi, lo);
+                mats[(e >> 6) * 128 + (e & 63)] = hi;
+                mats[(e >> 6) * 128 + 64 + (e & 63)] = lo;
+            }
+        }
+        if (threadIdx.x < LDF / 4) cvs[threadIdx.x] = *(const f32x4*)(a.colvec + (int64_t)bh * LDF + 4 * threadIdx.x);
     }
     fb_bf16x8 xh[2], xl[2];
 #pragma unroll
@@ -1464,36 +1483,53 @@ __global__ void __launch_bounds__(64 * FB_WAVES) attn_feat_bwd_kernel(FeatBwdArg
         xh[kh] = __builtin_bit_cast(fb_bf16x8, hi);
         xl[kh] = __builtin_bit_cast(fb_bf16x8, lo);
     }
+    // this lane's slice of the feature row (17 x 16 bytes, the only large HBM stream of the kernel), the row scale and the
+    // epilogue's source row: in flight while the first product runs
+    const float* fr = a.feat + row * LDF;
+    f32x4 fvv[17];
+#pragma unroll
+    for (int blk = 0; blk < 17; ++blk) {
+        fvv[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (16 * blk + 4 * g < NF && !(a.ablate & 1)) fvv[blk] = *(const f32x4*)(fr + 16 * blk + 4 * g);   // (rows are LDF = 268 floats: the last group that holds a feature is 264..267)
+    }
+    const float rs = QUERY ? a.rowscale[row] : 1.0f;
+    f32x4 s4[4];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) s4[blk] = *(const f32x4*)(a.src + row * DH + 16 * blk + 4 * g);
     __syncthreads();
-    if (f0 >= a.Fr) return;   // (the only barrier is behind us)
     f32x4 S[17];
 #pragma unroll
     for (int blk = 0; blk < 17; ++blk) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (active && !(a.ablate & 2)) {
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-            const ddsp_u32x4* p = mats + (blk * 2 + kh) * 128 + lane;
-            const fb_bf16x8 mh = __builtin_bit_cast(fb_bf16x8, p[0]), ml = __builtin_bit_cast(fb_bf16x8, p[64]);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ml, xh[kh], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mh, xl[kh], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mh, xh[kh], acc, 0, 0, 0);
+            for (int kh = 0; kh < 2; ++kh) {
+                const ddsp_u32x4* p = mats + (blk * 2 + kh) * 128 + lane;
+                const fb_bf16x8 mh = __builtin_bit_cast(fb_bf16x8, p[0]), ml = __builtin_bit_cast(fb_bf16x8, p[64]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ml, xh[kh], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mh, xl[kh], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mh, xh[kh], acc, 0, 0, 0);
+            }
         }
         S[blk] = acc;
     }
-    // feature-map adjoint on the registers (feature of S[blk][r]: 16 blk + 4 g + r)
-    const float rs = QUERY ? a.rowscale[row] : 1.0f;
-    const float* fr = a.feat + row * LDF;
-    const float* cv = a.colvec + (int64_t)bh * LDF;
+    __syncthreads();   // every wavefront is done with the matrix: the projection streams into the same region (no registers)
+#pragma unroll
+    for (int i = 0; i < FB_PT_VEC / 64 / FB_WAVES; ++i) {
+        const int piece = wave + FB_WAVES * i;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.pt + 64 * piece + lane),
+                                         (__attribute__((address_space(3))) void*)(pts + 64 * piece), 16, 0, 0);
+    }
+    static_assert(FB_PT_VEC % (64 * FB_WAVES) == 0, "whole 1 KiB pieces per wavefront");
+    // feature-map adjoint on the registers (feature of S[blk][r]: 16 blk + 4 g + r) while the projection arrives
     float t = 0.f, best = -3.0e38f;
     int arg = 0x7fffffff;
 #pragma unroll
     for (int blk = 0; blk < 17; ++blk) {
         const int j0 = 16 * blk + 4 * g;
-        f32x4 fv = {0.f, 0.f, 0.f, 0.f}, c4 = {0.f, 0.f, 0.f, 0.f};
-        if (j0 < NF) {   // (rows are LDF = 268 floats: the last group that holds a feature is 264..267)
-            fv = *(const f32x4*)(fr + j0);
-            c4 = *(const f32x4*)(cv + j0);
-        }
+        const f32x4 fv = fvv[blk];
+        f32x4 c4 = {0.f, 0.f, 0.f, 0.f};
+        if (j0 < NF) c4 = cvs[4 * blk + g];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool valid = j0 + r < NF;
@@ -1520,6 +1556,9 @@ __global__ void __launch_bounds__(64 * FB_WAVES) attn_feat_bwd_kernel(FeatBwdArg
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!active) return;
     f32x4 o4[4];
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) o4[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1541,6 +1580,7 @@ __global__ void __launch_bounds__(64 * FB_WAVES) attn_feat_bwd_kernel(FeatBwdArg
         ddsp_u32x4 hi, lo;
         ddsp_split8(y, hi, lo);
         const fb_bf16x8 yh = __builtin_bit_cast(fb_bf16x8, hi), yl = __builtin_bit_cast(fb_bf16x8, lo);
+        if (a.ablate & 4) continue;
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk) {
             const ddsp_u32x4* p = pts + (ks * 4 + blk) * 128 + lane;
@@ -1555,10 +1595,9 @@ __global__ void __launch_bounds__(64 * FB_WAVES) attn_feat_bwd_kernel(FeatBwdArg
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) {
         const int64_t off = row * DH + 16 * blk + 4 * g;
-        const f32x4 s4 = *(const f32x4*)(a.src + off);
         f32x4 r4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) r4[r] = fmaf(coef, s4[r], o4[blk][r]);
+        for (int r = 0; r < 4; ++r) r4[r] = fmaf(coef, s4[blk][r], o4[blk][r]);
         *(f32x4*)(a.out + off) = r4;
     }
 }
@@ -2934,13 +2973,14 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
             if (!(ctx->math != DDSP_MATH_FP32 && attn_wgrad_on()))
                 hipLaunchKernelGGL(weighted_key_sum_kernel, dim3((unsigned)(B * H)), dim3(KS_T * 8), 0, st, b.qf, dD, (int)Fr, dks);
             if (feat_fused) {   // d_q (in place of d_num, which the d_ctx launch above has consumed) and d_k: attn_feat_bwd_kernel
-                const dim3 fgrid((unsigned)((Fr + 16 * FB_WAVES - 1) / (16 * FB_WAVES)), (unsigned)(B * H));
+                const dim3 fgrid((unsigned)(B * H), (unsigned)((Fr + 16 * FB_WAVES - 1) / (16 * FB_WAVES)));
                 DDSP_ONCE_PER_DEVICE(ctx, DDSP_HIP(ctx, hipFuncSetAttribute((const void*)attn_feat_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES));
                                      DDSP_HIP(ctx, hipFuncSetAttribute((const void*)attn_feat_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES)));
                 const ddsp_u32x4* pt = reinterpret_cast<const ddsp_u32x4*>(ptp) + (size_t)l * FB_PT_VEC;
-                FeatBwdArgs fq{dB512, b.cx, dD, b.ks, b.qf, pt, b.q, dB512, (int)Fr};
+                static const int ablate = [] { const char* e = getenv("DDSP_FEAT_ABLATE"); return e ? atoi(e) : 0; }();
+                FeatBwdArgs fq{dB512, b.cx, dD, b.ks, b.qf, pt, b.q, dB512, (int)Fr, ablate};
                 hipLaunchKernelGGL(attn_feat_bwd_kernel<true>, fgrid, dim3(64 * FB_WAVES), FB_LDS_BYTES, st, fq);
-                FeatBwdArgs fk{b.v, dcx, nullptr, dks, b.kf, pt, b.k, dC512, (int)Fr};
+                FeatBwdArgs fk{b.v, dcx, nullptr, dks, b.kf, pt, b.k, dC512, (int)Fr, ablate};
                 hipLaunchKernelGGL(attn_feat_bwd_kernel<false>, fgrid, dim3(64 * FB_WAVES), FB_LDS_BYTES, st, fk);
             } else {   // d_k' = v d_ctx^T + d_ks^T
                 gemm::Args g = gemm::make(b.v, INNER, dcx, DH, (int)Fr, NF, DH);
