@@ -1392,6 +1392,8 @@ constexpr int FB_PT_VEC = FB_KS * 4 * 64 * 2;         // 16-byte vectors of one 
 __global__ void __launch_bounds__(256) feat_proj_prep_kernel(const float* __restrict__ P, ddsp_u32x4* __restrict__ dst) {
     const int idx = blockIdx.x * 256 + threadIdx.x;   // (ks, blk, lane)
     if (idx >= FB_KS * 4 * 64) return;
+    P += (int64_t)blockIdx.y * NF * DH;               // (blockIdx.y > 0: one (266, 64) matrix per (utterance, head) - d_ctx for the d_v product)
+    dst += (int64_t)blockIdx.y * FB_PT_VEC;
     const int lane = idx & 63, blk = (idx >> 6) & 3, ks = idx >> 8;
     const int d = 16 * blk + (lane & 15), g = lane >> 4;
     float x[8];
@@ -1415,6 +1417,8 @@ struct FeatBwdArgs {
     const float* src;        // q / k (M, 512)
     float* out;              // d_q / d_k (M, 512)
     int Fr;
+    const ddsp_u32x4* mat_t; // key side: d_ctx of every (utterance, head) in the projection's layout, for d_v = k' d_ctx; or null
+    float* out_v;            // d_v (M, 512)
     int ablate;              // timing experiments only (DDSP_FEAT_ABLATE): 1 no feature-row loads, 2 no first product, 4 no second product, 8 no staging
 };
 typedef __bf16 fb_bf16x8 __attribute__((ext_vector_type(8)));
@@ -1513,7 +1517,51 @@ __global__ void __launch_bounds__(64 * FB_WAVES, 2) attn_feat_bwd_kernel(FeatBwd
         }
         S[blk] = acc;
     }
-    __syncthreads();   // every wavefront is done with the matrix: the projection streams into the same region (no registers)
+    __syncthreads();   // every wavefront is done with the matrix
+    if (!QUERY && a.mat_t) {
+        // key side, d_v[n][d] = sum_j k'[n][j] d_ctx[j][d]: the lane's slice of k' is already the K operand (same slot order as
+        // d_feat below), d_ctx^T in the projection's layout (one launch of feat_proj_prep_kernel per layer) takes the region first
+        const ddsp_u32x4* src_t = a.mat_t + (int64_t)bh * FB_PT_VEC;
+#pragma unroll
+        for (int i = 0; i < FB_PT_VEC / 64 / FB_WAVES; ++i) {
+            const int piece = wave + FB_WAVES * i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_t + 64 * piece + lane),
+                                             (__attribute__((address_space(3))) void*)(pts + 64 * piece), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f32x4 o3[4];
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) o3[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (active) {
+#pragma unroll
+            for (int ks = 0; ks < FB_KS; ++ks) {
+                float y[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    y[r] = 32 * ks + 4 * g + r < NF ? fvv[2 * ks][r] : 0.f;
+                    y[4 + r] = (2 * ks + 1 < 17 && 32 * ks + 16 + 4 * g + r < NF) ? fvv[2 * ks + 1 < 17 ? 2 * ks + 1 : 16][r] : 0.f;
+                }
+                ddsp_u32x4 hi, lo;
+                ddsp_split8(y, hi, lo);
+                const fb_bf16x8 yh = __builtin_bit_cast(fb_bf16x8, hi), yl = __builtin_bit_cast(fb_bf16x8, lo);
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk) {
+                    const ddsp_u32x4* p = pts + (ks * 4 + blk) * 128 + lane;
+                    const fb_bf16x8 ph = __builtin_bit_cast(fb_bf16x8, p[0]), pl = __builtin_bit_cast(fb_bf16x8, p[64]);
+                    o3[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, yh, o3[blk], 0, 0, 0);
+                    o3[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, yl, o3[blk], 0, 0, 0);
+                    o3[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, yh, o3[blk], 0, 0, 0);
+                }
+            }
+            if (live) {
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk) *(f32x4*)(a.out_v + row * DH + 16 * blk + 4 * g) = o3[blk];
+            }
+        }
+        __syncthreads();   // done with d_ctx^T
+    }
+    // the projection streams into the same region (no registers)
 #pragma unroll
     for (int i = 0; i < FB_PT_VEC / 64 / FB_WAVES; ++i) {
         const int piece = wave + FB_WAVES * i;
@@ -2768,7 +2816,7 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
     // ---- arena: kept forward activations + backward temporaries ----
     U2CBufs bf;
     float *ctrl = nullptr, *dX, *dA, *dB512, *dC512, *dV512, *dG1, *dQF, *dKF, *dcx, *dks, *dD, *coefq, *coefk, *gx, *wpart, *cpart,
-        *dWh, *pk, *xs, *dwpart, *gbst, *w2t, *wts, *wpool, *ptp;
+        *dWh, *pk, *xs, *dwpart, *gbst, *w2t, *wts, *wpool, *ptp, *dcxt;
     // partial sums of the 18 Linear layers of the blocks, reduced by one launch at the end (WgDefer): 17 splits at most
     const size_t wpool_floats = (size_t)(WG_SPLITS + 1) * 3 * ((size_t)2 * D * INNER + (size_t)2 * INNER * D + (size_t)3 * INNER * D + 2 * D + 2 * INNER + 3 * INNER + 1024);
     auto plan_bwd = [&](Arena& a) {
@@ -2802,6 +2850,7 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
         wts = a.get((size_t)NO * D + 3 * ((size_t)2 * D * INNER + (size_t)2 * INNER * D + (size_t)3 * INNER * D));
         wpool = a.get(wpool_floats);
         ptp = a.get((size_t)3 * FB_PT_VEC * 4);   // prepared projections of attn_feat_bwd_kernel
+        dcxt = a.get((size_t)B * H * FB_PT_VEC * 4);   // d_ctx^T of every (utterance, head) in the same layout
     };
     if (keep) {
         Arena k{ctx, false, 0, 0, (char*)keep, keep_bytes};
@@ -2923,6 +2972,7 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
             hipLaunchKernelGGL(causal_attn_bwd_v_kernel, dim3((unsigned)(B * H)), dim3(256), 0, st, b.qf, b.kf, dB512, dD, (int)Fr,
                                dV512);
         } else {
+            bool dv_done = false;   // d_v folded into the key side of attn_feat_bwd_kernel
             hipLaunchKernelGGL(attn_out_bwd_kernel, dim3(rows8_g), dim3(256), 0, st, dB512, b.attn, b.dinv, M8, dD);  // d_num, d_D
             if (!feat_fused) {   // d_q' = d_num ctx^T + d_D ks^T
                 gemm::Args g = gemm::make(dB512, INNER, b.cx, DH, (int)Fr, NF, DH);
@@ -2978,9 +3028,15 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
                                      DDSP_HIP(ctx, hipFuncSetAttribute((const void*)attn_feat_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES)));
                 const ddsp_u32x4* pt = reinterpret_cast<const ddsp_u32x4*>(ptp) + (size_t)l * FB_PT_VEC;
                 static const int ablate = [] { const char* e = getenv("DDSP_FEAT_ABLATE"); return e ? atoi(e) : 0; }();
-                FeatBwdArgs fq{dB512, b.cx, dD, b.ks, b.qf, pt, b.q, dB512, (int)Fr, ablate};
+                static const bool fold_v = [] { const char* e = getenv("DDSP_ATTN_DV_FOLD"); return !(e && e[0] == '0'); }();
+                if (fold_v)
+                    hipLaunchKernelGGL(feat_proj_prep_kernel, dim3((FB_KS * 4 * 64 + 255) / 256, (unsigned)(B * H)), dim3(256), 0, st, dcx,
+                                       reinterpret_cast<ddsp_u32x4*>(dcxt));
+                dv_done = fold_v;
+                FeatBwdArgs fq{dB512, b.cx, dD, b.ks, b.qf, pt, b.q, dB512, (int)Fr, nullptr, nullptr, ablate};
                 hipLaunchKernelGGL(attn_feat_bwd_kernel<true>, fgrid, dim3(64 * FB_WAVES), FB_LDS_BYTES, st, fq);
-                FeatBwdArgs fk{b.v, dcx, nullptr, dks, b.kf, pt, b.k, dC512, (int)Fr, ablate};
+                FeatBwdArgs fk{b.v, dcx, nullptr, dks, b.kf, pt, b.k, dC512, (int)Fr,
+                               fold_v ? reinterpret_cast<const ddsp_u32x4*>(dcxt) : nullptr, dV512, ablate};
                 hipLaunchKernelGGL(attn_feat_bwd_kernel<false>, fgrid, dim3(64 * FB_WAVES), FB_LDS_BYTES, st, fk);
             } else {   // d_k' = v d_ctx^T + d_ks^T
                 gemm::Args g = gemm::make(b.v, INNER, dcx, DH, (int)Fr, NF, DH);
@@ -2992,7 +3048,7 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
                 EpiRowOuter e{dKF, nullptr, dks, (int)Fr};
                 attn_k64(st, g, (int)(B * H), e);
             }
-            {   // d_v = k' d_ctx
+            if (!dv_done) {   // d_v = k' d_ctx
                 gemm::Args g = gemm::make(b.kf, (int64_t)H * LDF, dcx, DH, (int)Fr, DH, NF);
                 g.zdiv = H;
                 g.sA_hi = (int64_t)Fr * H * LDF;
