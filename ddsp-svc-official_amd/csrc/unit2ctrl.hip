@@ -2639,7 +2639,12 @@ static int layer_grads(ddsp_ctx* ctx, hipStream_t st, const float* dY, int64_t l
     g.tap_shift = taps == 3 ? tap_shift : 0;
     g.Fr = Fr;
     g.M = M;
-    g.chunk = wgrad::chunk_for(M, WG_SPLITS);
+    static const int want_splits = [] {   // DDSP_WGRAD_SPLITS (1..16): row splits of a weight-gradient product (buffers are sized for 16)
+        const char* e = getenv("DDSP_WGRAD_SPLITS");
+        const int v = e ? atoi(e) : WG_SPLITS;
+        return v < 1 ? 1 : (v > WG_SPLITS ? WG_SPLITS : v);
+    }();
+    g.chunk = wgrad::chunk_for(M, want_splits);
     const int nz = wgrad::splits_for(M, g.chunk), N = taps * C;
     // deferred: partial sums into regions of the caller's pool, added up by ONE launch at the end of the backward pass
     float* dpart = nullptr;
