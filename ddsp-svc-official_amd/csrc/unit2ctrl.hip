@@ -2462,6 +2462,7 @@ __global__ void __launch_bounds__(256) reduce_partials_2d_kernel(const float* __
 // Deferred reductions (round 3): the 18 Linear layers of the three blocks write their split partial sums (and those of their bias
 // column sums) into regions of their own and ONE launch at the end of the backward pass adds them all up - 36 launches of 5-6 us
 // fewer per training step.  Same order of the additions (z ascending) as reduce_partials_2d_kernel.
+constexpr int WG_SPLITS = 16;   // row splits of a weight-gradient product (buffers and the reduction's register array are sized for it)
 constexpr int RED_JOBS_MAX = 48;
 struct RedJobs {
     int n;
@@ -2479,6 +2480,21 @@ __global__ void __launch_bounds__(256) reduce_jobs_kernel(RedJobs J) {
     float* __restrict__ out = J.dst[j];
     const int nz = J.nz[j], C = J.C[j];
     const int64_t n = (int64_t)J.O[j] * C, ldo = J.ldo[j];
+    if (nz <= WG_SPLITS + 1 && ((n | C | ldo) & 3) == 0 && (((uintptr_t)partial | (uintptr_t)out) & 15) == 0) {
+        // four outputs per thread and every split's load in flight before the first addition (same z-ascending order of the sums)
+        for (int64_t i = ((int64_t)((int)blockIdx.x - b0) * 256 + threadIdx.x) * 4; i < n; i += (int64_t)nb * 1024) {
+            f32x4 v[WG_SPLITS + 1];
+#pragma unroll
+            for (int z = 0; z < WG_SPLITS + 1; ++z)
+                if (z < nz) v[z] = *(const f32x4*)(partial + (int64_t)z * n + i);
+            f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int z = 0; z < WG_SPLITS + 1; ++z)
+                if (z < nz) s4 += v[z];
+            *(f32x4*)(out + (i / C) * ldo + (i % C)) = s4;
+        }
+        return;
+    }
     for (int64_t i = (int64_t)((int)blockIdx.x - b0) * 256 + threadIdx.x; i < n; i += (int64_t)nb * 256) {
         float s = 0.f;
         for (int z = 0; z < nz; ++z) s += partial[(int64_t)z * n + i];
@@ -2519,7 +2535,6 @@ static void flush_deferred(hipStream_t st, WgDefer& df) {
     df.used = 0;
 }
 
-constexpr int WG_SPLITS = 16;
 static int wgrad(ddsp_ctx* ctx, hipStream_t st, const float* dY, int64_t ldy, int O, const float* X, int64_t ldx, int C,
                  int64_t M, float* partial, float* out, int64_t ldo, int coff) {
     int64_t chunk = (M + WG_SPLITS - 1) / WG_SPLITS;
