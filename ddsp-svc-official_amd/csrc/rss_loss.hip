@@ -25,6 +25,52 @@ constexpr double kTwoPi = 6.283185307179586476925286766559;
 
 // tabT[col][i] (pitch Kp, zero for i >= N): the forward operand, k = i contiguous; tab[i][col] (pitch Kb, zero for
 // col >= 2 Mb; only when the gradient is wanted): the backward operand, k = col contiguous
+// The same tables from per-scale 1-D factors (round 3): t1 = [cos(2 pi j / N) | sin(2 pi j / N) | window_j / norm] in fp64, the very
+// expressions of stft_table_kernel, so the entries are bit-identical; an entry then costs an integer remainder and two loads instead
+// of three fp64 transcendentals (17 -> ~6 us per scale).
+constexpr int T1_SCALES = 8;
+struct Table1dArgs {
+    int n;
+    int N[T1_SCALES];
+    double* t1[T1_SCALES];   // 3 N doubles each
+};
+__global__ void __launch_bounds__(256) stft_table1d_kernel(Table1dArgs a) {
+    const int s = blockIdx.y;
+    if (s >= a.n) return;
+    const int N = a.N[s];
+    const double inv = 1.0 / sqrt(0.375 * (double)N);
+    double* __restrict__ t = a.t1[s];
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < N; j += gridDim.x * 256) {
+        const double ang = kTwoPi * (double)j / (double)N;
+        t[j] = cos(ang);
+        t[N + j] = sin(ang);
+        t[2 * N + j] = (0.5 - 0.5 * cos(kTwoPi * (double)j / (double)N)) * inv;
+    }
+}
+__global__ void stft_table_from1d_kernel(const double* __restrict__ t1, float* __restrict__ tabT, float* __restrict__ tab, int N,
+                                         int Kp, int Kb) {
+    const int Mb = N / 2 + 1;
+    const int64_t total = (int64_t)2 * Mb * Kp;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(idx / Kp), i = (int)(idx % Kp);
+        float v = 0.f;
+        if (i < N) {
+            const int f = col >> 1;
+            const int r = (int)(((unsigned)f * (unsigned)i) % (unsigned)N);   // f <= 4096, i < 8192
+            const double w = t1[2 * N + i];
+            v = (float)((col & 1) ? -w * t1[N + r] : w * t1[r]);
+            if (tab) tab[(int64_t)i * Kb + col] = v;
+        }
+        tabT[idx] = v;
+    }
+    if (tab) {
+        const int pad = Kb - 2 * Mb;
+        const int64_t tz = (int64_t)N * pad;
+        for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tz; idx += (int64_t)gridDim.x * blockDim.x)
+            tab[(idx / pad) * Kb + 2 * Mb + (idx % pad)] = 0.f;
+    }
+}
 __global__ void stft_table_kernel(float* __restrict__ tabT, float* __restrict__ tab, int N, int Kp, int Kb) {
     // norm = sqrt(sum_i hann_p(N)[i]^2) = sqrt(3N/8) (exact for N >= 3)
     const double inv = 1.0 / sqrt(0.375 * (double)N);
@@ -237,8 +283,13 @@ extern "C" int ddsp_rss_loss(ddsp_ctx* ctx, void* stream, const float* x_pred, c
     hipStream_t st = (hipStream_t)stream;
     DDSP_ENTER_DEVICE(ctx);
     // scratch sized for the worst scale: the two tables, the framed copy of both signals, S_t, S_p, X_p
+    static const bool table_1d = [] { const char* e = getenv("DDSP_LOSS_TABLE_1D"); return !(e && e[0] == '0'); }();
+    const bool use_1d = table_1d && n_scale <= T1_SCALES;
+    size_t t1_doubles = 0;
+    if (use_1d)
+        for (int s = 0; s < n_scale; ++s) t1_doubles += 3 * (size_t)n_ffts_host[s] + 2;
     int rc = ddsp_scratch_reserve_bytes(ctx, (tabT_f + tab_f + xf_f + 2 * s_f + xp_f) * sizeof(float) +
-                                                 (size_t)B * LS_CHUNKS * 3 * sizeof(double) + 16384);
+                                                 (size_t)B * LS_CHUNKS * 3 * sizeof(double) + t1_doubles * sizeof(double) + 16384);
     if (rc) return rc;
     ddsp_scratch_reset(ctx);
     float *tabT, *tab = nullptr, *Xf, *St, *Sp, *Xp = nullptr;
@@ -250,6 +301,17 @@ extern "C" int ddsp_rss_loss(ddsp_ctx* ctx, void* stream, const float* x_pred, c
     if ((rc = ddsp_scratch_get(ctx, s_f * sizeof(float), (void**)&Sp))) return rc;
     if (grad_pred && (rc = ddsp_scratch_get(ctx, xp_f * sizeof(float), (void**)&Xp))) return rc;
     if ((rc = ddsp_scratch_get(ctx, (size_t)B * LS_CHUNKS * 3 * sizeof(double), (void**)&stats))) return rc;
+    Table1dArgs t1a{};
+    if (use_1d) {
+        double* t1 = nullptr;
+        if ((rc = ddsp_scratch_get(ctx, t1_doubles * sizeof(double), (void**)&t1))) return rc;
+        t1a.n = n_scale;
+        for (int s = 0; s < n_scale; ++s) {
+            t1a.N[s] = n_ffts_host[s];
+            t1a.t1[s] = t1;
+            t1 += 3 * (size_t)n_ffts_host[s] + 2;
+        }
+    }
     // product arithmetic of the two DFT contractions: fp32 matrix products.  (The error of the spectra enters the gradient
     // through 1/S in near-empty bins, so the split-bf16 x3 class is not an option here; DDSP_LOSS_MATH=6 selects the
     // six-product form for measurements.)
@@ -275,7 +337,11 @@ extern "C" int ddsp_rss_loss(ddsp_ctx* ctx, void* stream, const float* x_pred, c
         const int F = (int)((T - N) / hop + 1);
         const int64_t M = B * F;
         const double weight = 1.0 / n_scale;
-        hipLaunchKernelGGL(stft_table_kernel, dim3(1024), dim3(256), 0, st, tabT, tab, N, Kp, Kb);
+        if (use_1d) {
+            if (s == 0) hipLaunchKernelGGL(stft_table1d_kernel, dim3(8, (unsigned)n_scale), dim3(256), 0, st, t1a);
+            hipLaunchKernelGGL(stft_table_from1d_kernel, dim3(1024), dim3(256), 0, st, t1a.t1[s], tabT, tab, N, Kp, Kb);
+        } else
+            hipLaunchKernelGGL(stft_table_kernel, dim3(1024), dim3(256), 0, st, tabT, tab, N, Kp, Kb);
         hipLaunchKernelGGL(frame_pad_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(2 * M * (Kp / 4), 256), 16384)), dim3(256),
                            0, st, x_true, x_pred, T, N, hop, F, M, Kp, Xf);
         if (Xp) DDSP_HIP(ctx, hipMemsetAsync(Xp, 0, (size_t)M * Kb * sizeof(float), st));   // (its pad columns multiply zeros of the table)

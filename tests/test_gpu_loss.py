@@ -148,3 +148,24 @@ def test_overlap_against_reference_run(ctx, dev):
     assert tail > 0 and torch.equal(grad[:, -tail:].cpu(), x64.grad[:, -tail:].float())   # exact zeros
     with pytest.raises(ValueError):
         ctx.rss_loss(xp.to(dev), xt.to(dev), [300], hops=[301])
+
+
+def test_tables_from_1d_factors_are_bit_identical(dev, lib_path):
+    """The DFT tables built from per-scale 1-D fp64 factors (round 3) are the tables of the per-entry kernel: loss value and
+    gradient of a four-scale call are equal bit for bit (DDSP_LOSS_TABLE_1D=0; child processes, the switch is read once)."""
+    import hashlib, os, subprocess, sys
+    code = (
+        "import sys, os, hashlib; sys.path.insert(0, os.path.join(%r, 'ddsp-svc-official_amd'));"
+        "import torch, hipddsp;"
+        "dev = torch.device('cuda:0'); g = torch.Generator().manual_seed(3);"
+        "xp = (0.1 * torch.randn(3, 8192, generator=g)).to(dev); xt = (0.1 * torch.randn(3, 8192, generator=g)).to(dev);"
+        "loss, grad = hipddsp.context_for(dev).rss_loss(xp, xt, [257, 1000, 2048, 333], want_grad=True);"
+        "print(hashlib.sha256(grad.cpu().numpy().tobytes()).hexdigest(), float(loss).hex())"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("1", "0"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DDSP_LOSS_TABLE_1D=flag), capture_output=True,
+                             text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append(out.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1], outs
