@@ -236,6 +236,8 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(const float* __restrict_
         const float k = mag > 0.f ? (float)g / mag : 0.f;
         xr[0] = k * re;
         xr[1] = k * im;
+        if (f == Mb - 1)   // the row's pad columns (they meet zero rows of the table in the adjoint product; < 32 of them)
+            for (int p = 2 * Mb; p < ldx; ++p) X[row * ldx + p] = 0.f;
     }
 }
 
@@ -344,7 +346,7 @@ extern "C" int ddsp_rss_loss(ddsp_ctx* ctx, void* stream, const float* x_pred, c
             hipLaunchKernelGGL(stft_table_kernel, dim3(1024), dim3(256), 0, st, tabT, tab, N, Kp, Kb);
         hipLaunchKernelGGL(frame_pad_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(2 * M * (Kp / 4), 256), 16384)), dim3(256),
                            0, st, x_true, x_pred, T, N, hop, F, M, Kp, Xf);
-        if (Xp) DDSP_HIP(ctx, hipMemsetAsync(Xp, 0, (size_t)M * Kb * sizeof(float), st));   // (its pad columns multiply zeros of the table)
+        // (the pad columns of Xp multiply zeros of the table: loss_grad_kernel clears them, the spectra kernel writes the rest)
         {
             gemm::Args g = gemm::make(Xf, Kp, tabT, Kp, (int)M, 2 * Mb, Kp);
             g.sA_hi = M * Kp;   // z = 0 target, 1 prediction
