@@ -1414,6 +1414,8 @@ struct FeatBwdArgs {
     const float* colvec;     // query side: ks (B*H, LDF);              key side: d_ks
     const float* feat;       // q' / k' (M8, LDF)
     const ddsp_u32x4* pt;    // prepared projection
+    const float* proj;       // query side: the projection as stored (NF, DH) - the arg-max term of the feature-map adjoint is the
+                             // rank-1 correction -dn t P[arg] of the epilogue (exact fp32) instead of 68 compares per lane
     const float* src;        // q / k (M, 512)
     float* out;              // d_q / d_k (M, 512)
     int Fr;
@@ -1580,7 +1582,7 @@ __global__ void __launch_bounds__(64 * FB_WAVES, 2) attn_feat_bwd_kernel(FeatBwd
         if (j0 < NF) c4 = cvs[4 * blk + g];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const bool valid = j0 + r < NF;
+            const bool valid = blk < 16 || j0 + r < NF;   // (only the last block holds pad features)
             const float E = QUERY ? fv[r] - ratio * 1e-4f : fv[r];
             const float dd = valid ? fmaf(rs, c4[r], S[blk][r]) * E : 0.f;
             S[blk][r] = dd;
@@ -1604,6 +1606,12 @@ __global__ void __launch_bounds__(64 * FB_WAVES, 2) attn_feat_bwd_kernel(FeatBwd
             }
         }
     }
+    f32x4 pa[4];
+    if (QUERY) {   // row `arg` of the projection (arg is the same in the four lanes of a frame), in flight under the second product
+        const int ja = arg < NF ? arg : 0;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) pa[blk] = *(const f32x4*)(a.proj + (int64_t)ja * DH + 16 * blk + 4 * g);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (!active) return;
@@ -1615,15 +1623,8 @@ __global__ void __launch_bounds__(64 * FB_WAVES, 2) attn_feat_bwd_kernel(FeatBwd
         float y[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float v0 = S[2 * ks][r];
-            if (QUERY && 32 * ks + 4 * g + r == arg) v0 -= t;
-            y[r] = dn * v0;
-            float v1 = 0.f;
-            if (2 * ks + 1 < 17) {
-                v1 = S[2 * ks + 1 < 17 ? 2 * ks + 1 : 16][r];
-                if (QUERY && 32 * ks + 16 + 4 * g + r == arg) v1 -= t;
-            }
-            y[4 + r] = dn * v1;
+            y[r] = dn * S[2 * ks][r];
+            y[4 + r] = 2 * ks + 1 < 17 ? dn * S[2 * ks + 1 < 17 ? 2 * ks + 1 : 16][r] : 0.f;
         }
         ddsp_u32x4 hi, lo;
         ddsp_split8(y, hi, lo);
@@ -1645,7 +1646,10 @@ __global__ void __launch_bounds__(64 * FB_WAVES, 2) attn_feat_bwd_kernel(FeatBwd
         const int64_t off = row * DH + 16 * blk + 4 * g;
         f32x4 r4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) r4[r] = fmaf(coef, s4[blk][r], o4[blk][r]);
+        for (int r = 0; r < 4; ++r) {
+            r4[r] = fmaf(coef, s4[blk][r], o4[blk][r]);
+            if (QUERY) r4[r] = fmaf(arg < NF ? -dn * t : 0.f, pa[blk][r], r4[r]);
+        }
         *(f32x4*)(a.out + off) = r4;
     }
 }
@@ -3053,9 +3057,9 @@ static int u2c_backward(ddsp_ctx* ctx, hipStream_t st, const ddsp_u2c_weights& w
                     hipLaunchKernelGGL(feat_proj_prep_kernel, dim3((FB_KS * 4 * 64 + 255) / 256, (unsigned)(B * H)), dim3(256), 0, st, dcx,
                                        reinterpret_cast<ddsp_u32x4*>(dcxt));
                 dv_done = fold_v;
-                FeatBwdArgs fq{dB512, b.cx, dD, b.ks, b.qf, pt, b.q, dB512, (int)Fr, nullptr, nullptr, ablate};
+                FeatBwdArgs fq{dB512, b.cx, dD, b.ks, b.qf, pt, L.proj, b.q, dB512, (int)Fr, nullptr, nullptr, ablate};
                 hipLaunchKernelGGL(attn_feat_bwd_kernel<true>, fgrid, dim3(64 * FB_WAVES), FB_LDS_BYTES, st, fq);
-                FeatBwdArgs fk{b.v, dcx, nullptr, dks, b.kf, pt, b.k, dC512, (int)Fr,
+                FeatBwdArgs fk{b.v, dcx, nullptr, dks, b.kf, pt, nullptr, b.k, dC512, (int)Fr,
                                fold_v ? reinterpret_cast<const ddsp_u32x4*>(dcxt) : nullptr, dV512, ablate};
                 hipLaunchKernelGGL(attn_feat_bwd_kernel<false>, fgrid, dim3(64 * FB_WAVES), FB_LDS_BYTES, st, fk);
             } else {   // d_k' = v d_ctx^T + d_ks^T
