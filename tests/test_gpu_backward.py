@@ -154,3 +154,8 @@ def test_unit2ctrl_parameter_gradients(dev, lib_path, B, Fr, spk_mode, causal):
         c.set_math(hipddsp.MATH_SPLIT_BF16)
     errs = sorted(((_rel(grads32[p].cpu(), sd[n].grad), n) for n, p in model.unit2ctrl.named_parameters()), reverse=True)
     assert errs[0][0] < 2e-3 and sum(e for e, _ in errs) / len(errs) < 3e-4, errs[:5]
+    # the two backward paths against each other: split arithmetic (batched weight-gradient kernel and the fused feature-map
+    # adjoint of the attention, round 3) and fp32 products on the unfused chain share the forward, so they differ by the product
+    # rounding of a linear map only
+    cross = sorted(((_rel(grads[p].cpu(), grads32[p].cpu()), n) for n, p in model.unit2ctrl.named_parameters()), reverse=True)
+    assert cross[0][0] < 5e-4, cross[:5]   # (measured: 2.1e-4 on to_q of the (2, 12) case, below 2e-4 elsewhere)
